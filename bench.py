@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the LSENeRF hot path on MI355X: train-step rays/sec on a 4096-ray x 1024-sample batch
+(BASELINE.json metric; SURVEY.md section 8d workload "M-march").
+
+One step = occupancy-grid ray marching (4-level 128^3 grid, fully occupied = the training regime of steps < 256,
+constant step, per-ray t_max capped so that every ray yields exactly 1024 samples) -> hash-grid field + fused MLPs
+forward -> packed volume rendering -> MSE(rgb, target) -> backward (incl. ray/pose gradients) -> [RCCL all-reduce of
+the flat gradient] -> fused Adam.  Synthetic rays, random-init parameters, fp32 throughout.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); per-GPU work is fixed (weak
+scaling): each rank renders its own 4096 rays and the gradient is all-reduced once per step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RAYS_PER_GPU = 4096
+SAMPLES_PER_RAY = 1024
+BYTES_PER_SAMPLE_STEP = 2136           # 1024 gather + 1024 scatter + 88 packed streams
+HASH_BYTES_PER_SAMPLE = 1024           # L*8*F*4: algorithmic bytes of one hash gather / scatter pass
+HBM_PEAK = 8.0e12                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_workload(device, seed):
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
+    torch.manual_seed(96)                                     # identical parameters on every rank
+    cfg = LSENeRFModelConfig(cone_angle=0.0, alpha_thre=0.0)  # M-march: constant step, no culling
+    model = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(device)
+    model.train()
+    model.occupancy_grid.mark_all_occupied()
+    g = torch.Generator().manual_seed(seed)                   # rank-dependent rays (R:train.py:104 seeds by rank)
+    R = RAYS_PER_GPU
+    o = (torch.rand(R, 3, generator=g) - 0.5)
+    d = torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    step = cfg.render_step_size
+    fars = torch.full((R, 1), cfg.near_plane + SAMPLES_PER_RAY * step - 0.25 * step)
+    target = torch.rand(R, 3, generator=g)
+    jitter = torch.zeros(R)                                   # fixed draw: sample count stays exactly 1024 per ray
+    rb = RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
+                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device), fars=fars.to(device),
+                   metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(device)})
+    return model, rb, target.to(device), jitter.to(device)
+
+
+def train_step(model, rb, target, jitter, opt, world):
+    from lsenerf_amd import dist as ldist
+    opt.zero_grad()
+    rb.origins.grad = None
+    rb.directions.grad = None
+    cfg = model.config
+    ri, ts, te, packed = model.occupancy_grid.sampling(
+        rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+        t_max=rb.fars.reshape(-1), render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
+        alpha_thre=cfg.alpha_thre, jitter=jitter, return_packed=True)
+    out = model.render_packed(rb, ri, ts, te, packed)
+    loss = torch.nn.functional.mse_loss(out["rgb"], target)
+    loss.backward()
+    if world > 1:
+        ldist.allreduce_grads(opt.flat.grad)
+    opt.step(grad_scale=1.0 / world)
+    return ri.shape[0], loss
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The reference's torch-native CPU field (nerfstudio HashEncoding.pytorch_fwd + nn.Linear MLPs + torch volrend,
+    restated in oracle/) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle.field import FieldOracle
+    from oracle.model import ModelOracle, cpu_train_step_packed
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    f = FieldOracle("torch", num_embeddings=64, seed=96)
+    m = ModelOracle(f, cone_angle=0.0, alpha_thre=0.0)
+    R = 32
+    g = torch.Generator().manual_seed(0)
+    o = torch.rand(R, 3, generator=g) - 0.5
+    d = torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    step = m.render_step_size
+    ri = torch.repeat_interleave(torch.arange(R), SAMPLES_PER_RAY)
+    ts = (0.05 + step * torch.arange(SAMPLES_PER_RAY, dtype=torch.float32)).repeat(R)
+    te = ts + step
+    target = torch.rand(R, 3, generator=g)
+    aid = torch.randint(0, 64, (R,), generator=g)
+    state = {}
+    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=16)      # warm-up
+    times = []
+    t_all = time.time()
+    while len(times) < 5 and (time.time() - t_all) < seconds_budget:
+        t0 = time.time()
+        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=16)
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": R / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{R} rays x {SAMPLES_PER_RAY} samples, {len(times)} timed train steps (median), torch-native field "
+                      f"(hash pytorch_fwd + nn.Linear MLPs + torch volrend + Adam), fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from lsenerf_amd import _lib, dist as ldist
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    import torch.distributed as tdist
+
+    rank, world, local = ldist.init_from_env("nccl")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    _lib.load()
+
+    model, rb, target, jitter = build_workload(device, seed=1000 + rank)
+    flat = FlatParams(model.get_param_groups()["fields"])
+    ldist.broadcast_params(flat.data)
+    opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
+
+    n_samples = 0
+    for _ in range(args.warmup):
+        n_samples, _ = train_step(model, rb, target, jitter, opt, world)
+
+    # timed region: barrier + synchronize on both sides, per-kernel HIP events on the launch stream
+    _lib.TIMING = {"names": {"lse_hash_bwd", "lse_hash_fwd", "lse_mlp_fwd", "lse_mlp_bwd", "lse_mlp_wgrad",
+                             "lse_volrend_fwd", "lse_volrend_bwd", "lse_traverse_grids", "lse_adam_step"}, "events": []}
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_samples, loss = train_step(model, rb, target, jitter, opt, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    elapsed = time.perf_counter() - t0
+    timing = _lib.TIMING
+    _lib.TIMING = None
+    elapsed = ldist.max_over_ranks(elapsed, device)
+
+    per_kernel = {}
+    for name, e0, e1 in timing["events"]:
+        per_kernel.setdefault(name, []).append(e0.elapsed_time(e1))
+    kern_ms = {k: sum(v) / args.steps for k, v in per_kernel.items()}           # ms per step (all launches of that entry)
+    launches = {k: len(v) / args.steps for k, v in per_kernel.items()}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        rays_per_s = world * RAYS_PER_GPU / (elapsed / args.steps)
+        assert n_samples == RAYS_PER_GPU * SAMPLES_PER_RAY, f"workload drifted: {n_samples} samples"
+        dom = max(("lse_hash_bwd", "lse_hash_fwd"), key=lambda k: kern_ms.get(k, 0.0))
+        dom_ms = kern_ms[dom] / max(launches[dom], 1)
+        achieved = HASH_BYTES_PER_SAMPLE * n_samples / (dom_ms * 1e-3) / 1e9
+        b_step = n_samples * BYTES_PER_SAMPLE_STEP + 8 * 4 * flat.numel
+        line = {
+            "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "M-march: LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, SH4, "
+                                   "32-d appearance embedding), 4096 rays/GPU x 1024 samples (4-level 128^3 grid fully "
+                                   "occupied, constant step), fwd+bwd+Adam, grads w.r.t. rays included",
+                       "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": SAMPLES_PER_RAY, "samples_per_step": n_samples,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples},
+            "step_roofline": {"algorithmic_bytes_per_step": b_step,
+                              "achieved_GBps": b_step / (ms_per_step * 1e-3) / 1e9 * 1.0,
+                              "frac_of_hbm_peak": b_step / (ms_per_step * 1e-3) / HBM_PEAK},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
+            "loss": float(loss),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * lse_hip.h -- C-ABI of the MI355X (gfx950) LSENeRF hot path.
+ *
+ * This is the drop-in boundary named by BASELINE.json `north_star`: the entry points below are what a
+ * Python binding replaces `tinycudann._C` and `nerfacc.cuda._C` with for the path
+ *     LSENeRFModel.exec_get_outputs            R:lse_nerf/lsenerf.py:278-326
+ *       -> LSEOccGridEstimator.sampling        R:lse_nerf/lse_grid_estimator.py:15-143
+ *       -> LSEField.get_density / get_outputs  R:lse_nerf/lse_field.py:264-360
+ *       -> nerfacc volrend + renderers         R:lse_nerf/lsenerf.py:300-318, R:lse_nerf/lse_renderer.py:4-10
+ * (`R:` = /root/reference/).  INTEGRATION.md shows the ctypes stubs a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with `h_` or it is a `*_desc` struct (host);
+ *   - tensors are dense row-major fp32 unless stated; sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it and
+ *     nothing synchronises: callers own ordering, memory and lifetime (no allocation inside the library);
+ *   - return value: 0 = OK, <0 = error (LSE_E_*), message via lse_last_error() (thread-local);
+ *   - functions marked "accumulate" add into their output (callers zero it), others overwrite.
+ */
+#ifndef LSE_HIP_H
+#define LSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSE_ABI_VERSION 1
+
+#define LSE_OK 0
+#define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
+#define LSE_E_LAUNCH (-2)    /* HIP launch / runtime error */
+#define LSE_E_UNSUPPORTED (-3)
+
+#define LSE_MAX_GRID_LEVELS 32
+#define LSE_MAX_OCC_LEVELS 8
+
+typedef void *lse_stream_t;
+
+/* ---- descriptors ------------------------------------------------------------------------------------ */
+
+/* tiny-cuda-nn HashGrid level table (replaces tcnn.Encoding(...) built at R:lse_nerf/lse_field.py:72-86).
+ * offsets are in ENTRIES of n_features floats; offsets[n_levels] = total entries. */
+typedef struct lse_grid_desc {
+    int32_t n_levels;
+    int32_t n_features;                              /* 2 */
+    uint32_t offsets[LSE_MAX_GRID_LEVELS + 1];
+    float scales[LSE_MAX_GRID_LEVELS];               /* grid_scale(level)            */
+    uint32_t resolutions[LSE_MAX_GRID_LEVELS];       /* grid_resolution(scale)       */
+} lse_grid_desc;
+
+#define LSE_IN_ROWMAJOR 0   /* in[N, n_in]                                                           */
+#define LSE_IN_LEVELMAJOR 1 /* in[n_in/2][N][2]  (the layout lse_hash_fwd writes)                      */
+#define LSE_ACT_NONE 0
+#define LSE_ACT_SIGMOID 1
+
+/* Bias-free fused MLP in tcnn parameter layout (replaces tcnn.Network via nerfstudio MLP,
+ * R:lse_nerf/lse_field.py:199-207 and :254-262): params = [W_0 (width x n_in) | W_h (width x width) x
+ * (n_hidden_layers-1) | W_out (16 x width)], each row-major [out,in].  Output always padded to 16. */
+typedef struct lse_mlp_desc {
+    int32_t n_in;            /* 8, 16, 32 or 64 (padded input width)                */
+    int32_t width;           /* 32 or 64                                            */
+    int32_t n_hidden_layers; /* 1 or 2                                              */
+    int32_t out_activation;  /* LSE_ACT_*                                           */
+    int32_t in_layout;       /* LSE_IN_*                                            */
+} lse_mlp_desc;
+
+/* ---- misc -------------------------------------------------------------------------------------------- */
+int lse_abi_version(void);
+const char *lse_last_error(void);
+
+/* ---- sampler: replaces nerfacc.grid.traverse_grids + the mask extraction at
+ *      R:lse_nerf/lse_grid_estimator.py:93-106.  Two passes like the upstream kernel:
+ *      mode 0 fills chunk_cnts[R]; mode 1 reads chunk_starts[R] and writes the packed samples.
+ *      binaries [levels, rx, ry, rz] uint8; aabbs [levels, 6]; near/far per ray.  Integer outputs are
+ *      bit-exact against oracle/c/lse_oracle.c.  ------------------------------------------------------ */
+int lse_traverse_grids(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
+                       const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
+                       const float *near_planes, const float *far_planes, float step_size, float cone_angle,
+                       int32_t mode, int64_t *chunk_cnts, const int64_t *chunk_starts, int32_t *ray_indices,
+                       float *t_starts, float *t_ends, lse_stream_t stream);
+
+/* nerfacc.pack_info (R:lse_nerf/lsenerf.py:300): packed_info[R,2] = (exclusive cumsum, count); total[1]. */
+int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info, int64_t *total,
+                              lse_stream_t stream);
+
+/* nerfacc.render_visibility_from_density (R:lse_nerf/lse_grid_estimator.py:120-127): mask[N] uint8 and the
+ * per-ray surviving counts new_cnts[R]. */
+int lse_visibility_mask(const float *t_starts, const float *t_ends, const float *sigmas,
+                        const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
+                        uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
+
+/* mask compaction at R:lse_nerf/lse_grid_estimator.py:139-143 (order preserving, per ray). */
+int lse_compact_samples(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info,
+                        int32_t n_rays, const int32_t *ray_indices, const float *t_starts, const float *t_ends,
+                        int32_t *out_ray_indices, float *out_t_starts, float *out_t_ends, lse_stream_t stream);
+
+/* ---- field ------------------------------------------------------------------------------------------- */
+
+/* R:lse_nerf/lse_field.py:266-274: pos = o[ri] + d[ri]*(ts+te)/2 -> L-inf contraction -> (x+2)/4 (contraction=1)
+ * or aabb normalisation (contraction=0, h_aabb[6]) -> selector -> x*selector.  ray_idx==NULL: rays_o holds N
+ * positions directly (Field.density_fn). */
+int lse_positions_fwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
+                      const float *t_ends, int64_t n, int32_t contraction, const float *h_aabb, float *x01,
+                      uint8_t *selector, lse_stream_t stream);
+/* d(pos)[N,3] from d(x01)[N,3] (Jacobian of contraction/normalisation, selector-masked). */
+int lse_positions_bwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
+                      const float *t_ends, int64_t n, int32_t contraction, const float *h_aabb, const float *d_x01,
+                      float *d_pos, lse_stream_t stream);
+/* per-ray sums: d_o[r] = sum d_pos, d_d[r] = sum d_pos*(ts+te)/2 over the ray's packed samples. */
+int lse_ray_grad_reduce(const float *d_pos, const float *t_starts, const float *t_ends, const int64_t *packed_info,
+                        int32_t n_rays, float *d_rays_o, float *d_rays_d, lse_stream_t stream);
+
+/* tcnn kernel_grid forward (R:lse_nerf/lse_field.py:279 via HashEncoding.forward): x01[N,3] -> y[L][N][F]. */
+int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const float *table, float *y, int64_t n,
+                 lse_stream_t stream);
+/* tcnn kernel_grid_backward (+_input): dtable accumulate (float atomics); dx[N,3] overwritten (NULL: skip). */
+int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
+                 float *dx, int64_t n, lse_stream_t stream);
+
+/* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
+ * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations [n_hidden_layers][N][width]. */
+int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
+                const int32_t *row_bias_idx, float *out, float *act, int64_t n, lse_stream_t stream);
+/* backward data path: d_out[N,16] (w.r.t. activated output) -> d_out_pre[N,16], d_act[n_hidden_layers][N][width]
+ * (w.r.t. pre-activations), d_in (layout of desc->in_layout; nullable). */
+int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *act, const float *out, const float *d_out,
+                float *d_out_pre, float *d_act, float *d_in, int64_t n, lse_stream_t stream);
+/* weight gradients, accumulate into d_params (same layout as params). */
+int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
+                  const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream);
+/* out[R,width] += per-ray sum of d_act0[N,width] (gradient of row_bias). */
+int lse_segment_sum_rows(const float *rows, int32_t width, const int64_t *packed_info, int32_t n_rays, float *out,
+                         lse_stream_t stream);
+
+/* per-ray head features in tcnn column order [SH16(dir) | 15 zeros (geo slots) | emb(32) | 1]
+ * (R:lse_nerf/lse_field.py:298-300, 306-310, 347-356; SH of tcnn, degree 4). emb_table NULL -> zeros. */
+int lse_ray_features_fwd(const float *rays_d, const float *emb_table, const int32_t *emb_idx, int32_t n_rays,
+                         int32_t emb_dim, float *feat, lse_stream_t stream);
+int lse_ray_features_bwd(const float *rays_d, const float *d_feat, const int32_t *emb_idx, int32_t n_rays,
+                         int32_t emb_dim, float *d_rays_d, float *d_emb_table, lse_stream_t stream);
+/* small dense helpers on per-ray matrices: y[R,M] = x[R,K] W[M,K]^T ; dx[R,K] = dy[R,M] W[M,K] ;
+ * dW[M,K] += dy^T x. */
+int lse_linear_fwd(const float *w, const float *x, int32_t rows, int32_t m, int32_t k, float *y, lse_stream_t stream);
+int lse_linear_bwd_input(const float *w, const float *dy, int32_t rows, int32_t m, int32_t k, float *dx,
+                         lse_stream_t stream);
+int lse_gemm_tn_acc(const float *g, int32_t m, const float *a, int32_t k, int32_t a_layout, int64_t n, float *dw,
+                    int32_t dw_ld, lse_stream_t stream);
+
+/* density = scale * exp(h[:,0]) * selector (trunc_exp, R:lse_nerf/lse_field.py:286-287); h is [N,16]. */
+int lse_density_fwd(const float *h, const uint8_t *selector, float scale, float *sigma, int64_t n, lse_stream_t stream);
+/* d_h[:,0] = d_sigma * scale * exp(clamp(h0,-15,15)) * selector (overwrites column 0 only). */
+int lse_density_bwd(const float *h, const uint8_t *selector, float scale, const float *d_sigma, float *d_h, int64_t n,
+                    lse_stream_t stream);
+
+/* ---- renderer: nerfacc.render_weight_from_density + accumulate_along_rays
+ *      (R:lse_nerf/lsenerf.py:301-318, R:lse_nerf/lse_renderer.py:6-10).  rgb has row stride rgb_stride floats. */
+int lse_volrend_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                    int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, float *weights, float *out_rgb,
+                    float *out_acc, float *out_depth_num, lse_stream_t stream);
+int lse_volrend_bwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                    int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, const float *weights,
+                    const float *d_out_rgb, const float *d_out_acc, const float *d_out_depth_num, float *d_sigmas,
+                    float *d_rgb, lse_stream_t stream);
+
+/* ---- occupancy grid (nerfacc OccGridEstimator._update) --------------------------- */
+/* occs[id] = max(occs[id]*ema_decay, occ_new); duplicate ids resolve to the maximum over the duplicates (upstream:
+ * an arbitrary one of them wins).  workspace: n floats. */
+int lse_occ_update_cells(float *occs, const int64_t *cell_ids, const float *occ_new, int64_t n, float ema_decay,
+                         float *workspace, lse_stream_t stream);
+int lse_occ_binarize(const float *occs, int64_t n, const float *d_threshold, uint8_t *binaries, lse_stream_t stream);
+
+/* ---- optimiser: torch.optim.Adam semantics on a flat buffer (R:lse_nerf/lse_config.py:29-33) ----------- */
+int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSE_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI in include/lse_hip.h (liblse_hip.so, gfx950).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  The CPU oracle under
+``oracle/`` is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblse_hip.so")
+
+LSE_MAX_GRID_LEVELS = 32
+LSE_MAX_OCC_LEVELS = 8
+LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
+LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
+LSE_ABI_VERSION = 1
+
+
+class GridDesc(Structure):
+    _fields_ = [("n_levels", c_int32), ("n_features", c_int32), ("offsets", c_uint32 * (LSE_MAX_GRID_LEVELS + 1)),
+                ("scales", c_float * LSE_MAX_GRID_LEVELS), ("resolutions", c_uint32 * LSE_MAX_GRID_LEVELS)]
+
+
+class MlpDesc(Structure):
+    _fields_ = [("n_in", c_int32), ("width", c_int32), ("n_hidden_layers", c_int32), ("out_activation", c_int32),
+                ("in_layout", c_int32)]
+
+
+P = c_void_p
+I32, I64, F32 = c_int32, c_int64, c_float
+
+# name -> argtypes (all return int except the two misc functions); mirrors include/lse_hip.h one to one
+SIGNATURES = {
+    "lse_traverse_grids": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I32, P, P, P, P, P, P],
+    "lse_pack_info_from_counts": [P, I32, P, P, P],
+    "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
+    "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
+    "lse_positions_fwd": [P, P, P, P, P, I64, I32, P, P, P, P],
+    "lse_positions_bwd": [P, P, P, P, P, I64, I32, P, P, P, P],
+    "lse_ray_grad_reduce": [P, P, P, P, I32, P, P, P],
+    "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P],
+    "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P],
+    "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, P, I64, P],
+    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, P, P, P, P, I64, P],
+    "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
+    "lse_segment_sum_rows": [P, I32, P, I32, P, P],
+    "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],
+    "lse_ray_features_bwd": [P, P, P, I32, I32, P, P, P],
+    "lse_linear_fwd": [P, P, I32, I32, I32, P, P],
+    "lse_linear_bwd_input": [P, P, I32, I32, I32, P, P],
+    "lse_gemm_tn_acc": [P, I32, P, I32, I32, I64, P, I32, P],
+    "lse_density_fwd": [P, P, F32, P, I64, P],
+    "lse_density_bwd": [P, P, F32, P, P, I64, P],
+    "lse_volrend_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P],
+    "lse_volrend_bwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P],
+    "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
+    "lse_occ_binarize": [P, I64, P, P, P],
+    "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],
+}
+
+_lib = None
+
+
+class LseHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblse_hip.so (built by ``__graft_entry__.build()`` / ``make -C lsenerf_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LseHipError(
+            f"{LIB_PATH} not found: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C lsenerf_amd/csrc`).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.lse_last_error.restype = c_char_p
+    lib.lse_last_error.argtypes = []
+    lib.lse_abi_version.restype = c_int32
+    lib.lse_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here == header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = c_int32
+    v = lib.lse_abi_version()
+    if v != LSE_ABI_VERSION:
+        raise LseHipError(f"liblse_hip.so ABI version {v} != binding version {LSE_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+# bench.py sets this to {"names": set, "events": []}: the named entry points are then bracketed by HIP events
+# recorded on torch's current stream (the stream every kernel is launched on).
+TIMING = None
+
+
+def call(name: str, *args):
+    lib = load()
+    t = TIMING
+    if t is not None and name in t["names"]:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        t["events"].append((name, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise LseHipError(f"{name} failed (rc={rc}): {lib.lse_last_error().decode()}")

@@ -1,0 +1,56 @@
+// Shared host/device helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <algorithm>
+#include "../../include/lse_hip.h"
+
+namespace lse {
+
+void set_error(const char *fmt, ...);
+
+static inline hipStream_t as_stream(lse_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return LSE_E_LAUNCH;
+    }
+    return LSE_OK;
+}
+
+#define LSE_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            lse::set_error(__VA_ARGS__);  \
+            return LSE_E_INVALID;         \
+        }                                 \
+    } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave-wide inclusive scan (sum) over 64 lanes
+__device__ __forceinline__ float wave_inclusive_sum(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float n = __shfl_up(v, off, 64);
+        if (lane_id() >= off) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace lse

@@ -1,0 +1,657 @@
+// Fused small MLPs on the gfx950 f32 matrix cores (v_mfma_f32_16x16x4_f32) -- the kernels behind
+// `tcnn.Network` as nerfstudio's MLP configures it at R:lse_nerf/lse_field.py:199-207 (mlp_base_mlp) and
+// :254-262 (mlp_head): bias-free, ReLU hidden layers, optional sigmoid output, tcnn parameter layout.
+//
+// Orientation.  Every layer is computed transposed, H^T = W * X^T, so that the 64 SAMPLES of a wave tile sit on
+// the MFMA column (lane) dimension and the NEURONS sit on the accumulator registers:
+//     C/D of 16x16x4:  col = lane & 15 (sample),  row = 4*(lane>>4) + reg (neuron within a 16-row block).
+// A following layer needs B[k][col] = H[sample col][neuron k] with lane (col, q) supplying one k per k-step.
+// Choosing the k order  kidx(ks, q) = 16*(ks>>2) + 4*q + (ks&3)  makes that operand exactly register (ks&3) of
+// row block (ks>>2) of the previous accumulator: layers chain in registers with no LDS traffic and no
+// cross-lane moves.  The weight (A) operands are pre-permuted to the same k order when the workgroup stages them
+// into LDS ("A images": 64 floats per (row block, k-step), read conflict-free with one ds_read_b32 per MFMA
+// group and reused for the 4 column tiles of the wave).
+//
+// fp32 MFMA runs at the fp32 VALU rate (157 TF peak): the win is register/issue economy and exact f32
+// (bitwise a k-ordered fmaf chain), which is what the reference's float32 tcnn build computes.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LSE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// k order of a 16-column block read as float4 per lane / of a chained accumulator
+__device__ __host__ __forceinline__ constexpr int kidx_blk(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }
+// k order of level-major hash features read as float2 per lane: lane q of k-step pair m reads level 4m+q
+__device__ __host__ __forceinline__ constexpr int kidx_hash(int ks, int q) { return 8 * (ks >> 1) + 2 * q + (ks & 1); }
+
+template <int INL>
+__device__ __forceinline__ constexpr int kidx_in(int ks, int q)
+{
+    return INL == LSE_IN_LEVELMAJOR ? kidx_hash(ks, q) : kidx_blk(ks, q);
+}
+
+struct MlpArgs {
+    const float *params;
+    const float *in;
+    const float *row_bias;
+    const int32_t *row_bias_idx;
+    float *out;
+    float *act;
+    int64_t n;
+    int out_activation;
+    // backward
+    const float *d_out;
+    float *d_out_pre;
+    float *d_act;
+    float *d_in;
+};
+
+constexpr int kCT = 4;   // column tiles (of 16 samples) per wave iteration -> 64 samples
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+template <int KIN, int WIDTH, int NHL, int INL>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
+{
+    constexpr int HB = WIDTH / 16, KS0 = KIN / 4, KSH = WIDTH / 4;
+    constexpr int IMG0 = HB * KS0, IMGH = (NHL == 2) ? HB * KSH : 0, IMGO = KSH;
+    extern __shared__ float lds[];
+    float *img0 = lds, *imgH = lds + IMG0 * 64, *imgO = imgH + IMGH * 64;
+
+    const float *W0 = a.params;
+    const float *W1 = W0 + WIDTH * KIN;
+    const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
+    for (int e = threadIdx.x; e < IMG0 * 64; e += 256) {
+        const int img = e >> 6, ln = e & 63, rb = img / KS0, ks = img % KS0, i = ln & 15, q = ln >> 4;
+        img0[e] = W0[(16 * rb + i) * KIN + kidx_in<INL>(ks, q)];
+    }
+    if (NHL == 2)
+        for (int e = threadIdx.x; e < IMGH * 64; e += 256) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            imgH[e] = W1[(16 * rb + i) * WIDTH + kidx_blk(ks, q)];
+        }
+    for (int e = threadIdx.x; e < IMGO * 64; e += 256) {
+        const int ks = e >> 6, ln = e & 63, i = ln & 15, q = ln >> 4;
+        imgO[e] = Wo[i * WIDTH + kidx_blk(ks, q)];
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int64_t n = a.n;
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t s[kCT];
+        bool valid[kCT];
+#pragma unroll
+        for (int ct = 0; ct < kCT; ++ct) {
+            const int64_t si = tile * 64 + ct * 16 + j;
+            valid[ct] = si < n;
+            s[ct] = valid[ct] ? si : n - 1;
+        }
+        // ---- layer-0 B operands: breg[ct][ks] = in[sample][kidx_in(ks, q)]
+        float breg[kCT][KS0];
+#pragma unroll
+        for (int ct = 0; ct < kCT; ++ct) {
+            if (INL == LSE_IN_LEVELMAJOR) {
+#pragma unroll
+                for (int m = 0; m < KIN / 8; ++m) {
+                    const float2 v = reinterpret_cast<const float2 *>(a.in)[(int64_t)(4 * m + q) * n + s[ct]];
+                    breg[ct][2 * m] = v.x;
+                    breg[ct][2 * m + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < KIN / 16; ++b) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(a.in + s[ct] * KIN + 16 * b + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) breg[ct][4 * b + r] = v[r];
+                }
+            }
+        }
+        // ---- layer 0
+        f32x4 h[HB][kCT];
+        if (a.row_bias) {
+#pragma unroll
+            for (int ct = 0; ct < kCT; ++ct) {
+                const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[s[ct]] : s[ct];
+#pragma unroll
+                for (int rb = 0; rb < HB; ++rb)
+                    h[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) h[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) {
+                const float aw = img0[(rb * KS0 + ks) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) h[rb][ct] = LSE_MFMA(aw, breg[ct][ks], h[rb][ct]);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < kCT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h[rb][ct][r], 0.f);
+                if (a.act && valid[ct])
+                    *reinterpret_cast<f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q) = h[rb][ct];
+            }
+        // ---- hidden layer (width x width)
+        if (NHL == 2) {
+            f32x4 h2[HB][kCT];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) h2[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < HB; ++rb) {
+                        const float aw = imgH[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < kCT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
+                    }
+                }
+            float *act1 = a.act ? a.act + n * WIDTH : nullptr;
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h2[rb][ct][r], 0.f);
+                    if (act1 && valid[ct])
+                        *reinterpret_cast<f32x4 *>(act1 + s[ct] * WIDTH + 16 * rb + 4 * q) = h[rb][ct];
+                }
+        }
+        // ---- output layer (16 x width)
+        f32x4 o[kCT];
+#pragma unroll
+        for (int ct = 0; ct < kCT; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float aw = imgO[(4 * bp + r) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) o[ct] = LSE_MFMA(aw, h[bp][ct][r], o[ct]);
+            }
+#pragma unroll
+        for (int ct = 0; ct < kCT; ++ct) {
+            if (a.out_activation == LSE_ACT_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[ct][r] = 1.f / (1.f + __expf(-o[ct][r]));
+            }
+            if (valid[ct]) *reinterpret_cast<f32x4 *>(a.out + s[ct] * 16 + 4 * q) = o[ct];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward data path:  dOut -> dH_last -> (dH_0) -> dIn, all chained in registers with transposed A images
+// ------------------------------------------------------------------------------------------------------
+template <int KIN, int WIDTH, int NHL, int INL>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
+{
+    constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
+    constexpr int RB0 = (KIN + 15) / 16;
+    constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
+    extern __shared__ float lds[];
+    float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
+
+    const float *W0 = a.params;
+    const float *W1 = W0 + WIDTH * KIN;
+    const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
+    // dH_last^T = Wo^T (WIDTH x 16) * dOut^T : A[i][k] = Wo[k = 4q+ks][16rb+i]
+    for (int e = threadIdx.x; e < IMGO * 64; e += 256) {
+        const int img = e >> 6, ln = e & 63, rb = img >> 2, ks = img & 3, i = ln & 15, q = ln >> 4;
+        imgO[e] = Wo[(4 * q + ks) * WIDTH + 16 * rb + i];
+    }
+    if (NHL == 2)   // dH_0^T = W1^T * dH_1^T : A[i][k] = W1[kidx_blk(ks,q)][16rb+i]
+        for (int e = threadIdx.x; e < IMGH * 64; e += 256) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            imgH[e] = W1[kidx_blk(ks, q) * WIDTH + 16 * rb + i];
+        }
+    if (a.d_in)     // dIn^T = W0^T (KIN x WIDTH) * dH_0^T : A[i][k] = W0[kidx_blk(ks,q)][16rb+i]
+        for (int e = threadIdx.x; e < IMGI * 64; e += 256) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            const int col = 16 * rb + i;
+            imgI[e] = col < KIN ? W0[kidx_blk(ks, q) * KIN + col] : 0.f;
+        }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int64_t n = a.n;
+    const int64_t n_tiles = (n + 63) / 64;
+    const float *act_last = a.act + (int64_t)(NHL - 1) * n * WIDTH;
+    float *dact_last = a.d_act + (int64_t)(NHL - 1) * n * WIDTH;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t s[kCT];
+        bool valid[kCT];
+        f32x4 g[kCT];
+#pragma unroll
+        for (int ct = 0; ct < kCT; ++ct) {
+            const int64_t si = tile * 64 + ct * 16 + j;
+            valid[ct] = si < n;
+            s[ct] = valid[ct] ? si : n - 1;
+            g[ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
+            if (a.out_activation == LSE_ACT_SIGMOID) {
+                const f32x4 ov = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[ct][r] = g[ct][r] * ov[r] * (1.f - ov[r]);
+            }
+            if (valid[ct]) *reinterpret_cast<f32x4 *>(a.d_out_pre + s[ct] * 16 + 4 * q) = g[ct];
+        }
+        // ---- dH_last
+        f32x4 dh[HB][kCT];
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < kCT; ++ct) dh[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) {
+                const float aw = imgO[(rb * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) dh[rb][ct] = LSE_MFMA(aw, g[ct][r], dh[rb][ct]);
+            }
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < kCT; ++ct) {
+                const f32x4 hv = *reinterpret_cast<const f32x4 *>(act_last + s[ct] * WIDTH + 16 * rb + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[r] > 0.f ? dh[rb][ct][r] : 0.f;
+                if (valid[ct]) *reinterpret_cast<f32x4 *>(dact_last + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+            }
+        // ---- dH_0 (two hidden layers)
+        if (NHL == 2) {
+            f32x4 d0[HB][kCT];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) d0[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < HB; ++rb) {
+                        const float aw = imgH[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < kCT; ++ct) d0[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], d0[rb][ct]);
+                    }
+                }
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) {
+                    const f32x4 hv = *reinterpret_cast<const f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[r] > 0.f ? d0[rb][ct][r] : 0.f;
+                    if (valid[ct]) *reinterpret_cast<f32x4 *>(a.d_act + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                }
+        }
+        // ---- dIn
+        if (a.d_in) {
+            f32x4 di[RB0][kCT];
+#pragma unroll
+            for (int rb = 0; rb < RB0; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) di[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < RB0; ++rb) {
+                        const float aw = imgI[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < kCT; ++ct) di[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], di[rb][ct]);
+                    }
+                }
+#pragma unroll
+            for (int rb = 0; rb < RB0; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < kCT; ++ct) {
+                    if (!valid[ct]) continue;
+                    if (INL == LSE_IN_LEVELMAJOR) {
+                        // rows 16rb+4q+r are features; feature f -> level f>>1, component f&1
+                        if (16 * rb + 4 * q < KIN) {
+                            float2 *d2 = reinterpret_cast<float2 *>(a.d_in);
+                            const int lv = 8 * rb + 2 * q;
+                            d2[(int64_t)lv * n + s[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
+                            d2[(int64_t)(lv + 1) * n + s[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
+                        }
+                    } else {
+                        if (16 * rb + 4 * q < KIN)
+                            *reinterpret_cast<f32x4 *>(a.d_in + s[ct] * KIN + 16 * rb + 4 * q) = di[rb][ct];
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradients:  dW[M x K] += G[N x M]^T * A[N x K]   (samples are the MFMA k dimension, so both
+// operands are read straight from their row-major rows: lane (i, q) of k-step s reads row 4s+q, column i)
+// ------------------------------------------------------------------------------------------------------
+template <int M, int K, int AL>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict__ G, const float *__restrict__ A,
+                                                         int64_t n, float *__restrict__ dW, int dw_ld)
+{
+    constexpr int MB = M / 16, KB = (K + 15) / 16;
+    __shared__ float red[M * KB * 16];
+    for (int e = threadIdx.x; e < M * KB * 16; e += 256) red[e] = 0.f;
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    f32x4 acc[MB][KB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t n_steps = (n + 3) / 4;
+    const int64_t total_waves = (int64_t)gridDim.x * 4;
+    const int64_t per = (n_steps + total_waves - 1) / total_waves;
+    const int64_t w_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t s_lo = w_id * per, s_hi = min(n_steps, s_lo + per);
+    constexpr int U = 2;
+    for (int64_t st = s_lo; st < s_hi; st += U) {
+        float av[U][MB], bv[U][KB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = (st + u) * 4 + q;
+            const bool ok = (st + u) < s_hi && row < n;
+            const int64_t rr = ok ? row : 0;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const float v = G[rr * M + 16 * mb + i];
+                av[u][mb] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int col = 16 * kb + i;
+                float v = 0.f;
+                if (col < K) {
+                    if (AL == LSE_IN_LEVELMAJOR) v = A[((int64_t)(col >> 1) * n + rr) * 2 + (col & 1)];
+                    else v = A[rr * K + col];
+                }
+                bv[u][kb] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc[mb][kb] = LSE_MFMA(av[u][mb], bv[u][kb], acc[mb][kb]);
+    }
+    // D: col = lane&15 -> A column, row = 4q + r -> G column
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mb + 4 * q + r) * (KB * 16) + 16 * kb + i], acc[mb][kb][r]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < M * KB * 16; e += 256) {
+        const int row = e / (KB * 16), col = e % (KB * 16);
+        if (col < K) atomicAdd(&dW[row * dw_ld + col], red[e]);
+    }
+}
+
+// per-ray sums of rows[N, width] over packed segments: one wave per ray, lane = column
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ rows, int width,
+                                                               const int64_t *__restrict__ packed, int n_rays,
+                                                               float *__restrict__ out)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    if (lane >= width) return;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int64_t k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        acc0 += rows[(s0 + k) * width + lane];
+        acc1 += rows[(s0 + k + 1) * width + lane];
+        acc2 += rows[(s0 + k + 2) * width + lane];
+        acc3 += rows[(s0 + k + 3) * width + lane];
+    }
+    for (; k < cnt; ++k) acc0 += rows[(s0 + k) * width + lane];
+    out[(int64_t)ray * width + lane] += (acc0 + acc1) + (acc2 + acc3);
+}
+
+// small dense helpers on per-ray matrices (R x <=64): one thread per output element
+__global__ void linear_fwd_kernel(const float *__restrict__ w, const float *__restrict__ x, int rows, int m, int k,
+                                  float *__restrict__ y)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)rows * m) return;
+    const int r = e / m, o = e % m;
+    float acc = 0.f;
+    for (int c = 0; c < k; ++c) acc = fmaf(x[(int64_t)r * k + c], w[o * k + c], acc);
+    y[e] = acc;
+}
+
+__global__ void linear_bwd_input_kernel(const float *__restrict__ w, const float *__restrict__ dy, int rows, int m,
+                                        int k, float *__restrict__ dx)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)rows * k) return;
+    const int r = e / k, c = e % k;
+    float acc = 0.f;
+    for (int o = 0; o < m; ++o) acc = fmaf(dy[(int64_t)r * m + o], w[o * k + c], acc);
+    dx[e] = acc;
+}
+
+int check_desc(const lse_mlp_desc *d, const char *who)
+{
+    LSE_REQUIRE(d, "%s: null desc", who);
+    LSE_REQUIRE(d->n_in == 8 || d->n_in == 16 || d->n_in == 32 || d->n_in == 64, "%s: n_in %d not in {8,16,32,64}",
+                who, d->n_in);
+    LSE_REQUIRE(d->width == 32 || d->width == 64, "%s: width %d not in {32,64}", who, d->width);
+    LSE_REQUIRE(d->n_hidden_layers == 1 || d->n_hidden_layers == 2, "%s: n_hidden_layers %d not in {1,2}", who,
+                d->n_hidden_layers);
+    LSE_REQUIRE(d->in_layout == LSE_IN_ROWMAJOR || d->in_layout == LSE_IN_LEVELMAJOR, "%s: bad in_layout", who);
+    LSE_REQUIRE(d->in_layout == LSE_IN_LEVELMAJOR || d->n_in >= 16, "%s: row-major input needs n_in >= 16", who);
+    LSE_REQUIRE(d->out_activation == LSE_ACT_NONE || d->out_activation == LSE_ACT_SIGMOID, "%s: bad out_activation",
+                who);
+    return LSE_OK;
+}
+
+template <int KIN, int WIDTH, int NHL, int INL>
+int launch_fwd(const MlpArgs &a, hipStream_t st)
+{
+    constexpr int HB = WIDTH / 16;
+    constexpr int imgs = HB * (KIN / 4) + (NHL == 2 ? HB * (WIDTH / 4) : 0) + WIDTH / 4;
+    const int64_t tiles = (a.n + 63) / 64;
+    const int blocks = (int)std::min<int64_t>((tiles + 3) / 4, 2048);
+    hipLaunchKernelGGL((mlp_fwd_kernel<KIN, WIDTH, NHL, INL>), dim3(blocks), dim3(256), imgs * 256, st, a);
+    return lse::check_launch("lse_mlp_fwd");
+}
+
+template <int KIN, int WIDTH, int NHL, int INL>
+int launch_bwd(const MlpArgs &a, hipStream_t st)
+{
+    constexpr int HB = WIDTH / 16;
+    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4);
+    const int64_t tiles = (a.n + 63) / 64;
+    const int blocks = (int)std::min<int64_t>((tiles + 3) / 4, 2048);
+    hipLaunchKernelGGL((mlp_bwd_kernel<KIN, WIDTH, NHL, INL>), dim3(blocks), dim3(256), imgs * 256, st, a);
+    return lse::check_launch("lse_mlp_bwd");
+}
+
+#define LSE_MLP_DISPATCH(FN, d, a, st)                                                                   \
+    do {                                                                                                 \
+        const int key = (d)->n_in * 1000 + (d)->width * 10 + (d)->n_hidden_layers;                        \
+        if ((d)->in_layout == LSE_IN_LEVELMAJOR) {                                                       \
+            switch (key) {                                                                               \
+            case 32641: return FN<32, 64, 1, LSE_IN_LEVELMAJOR>(a, st);                                  \
+            case 32642: return FN<32, 64, 2, LSE_IN_LEVELMAJOR>(a, st);                                  \
+            case 8321: return FN<8, 32, 1, LSE_IN_LEVELMAJOR>(a, st);                                    \
+            case 8641: return FN<8, 64, 1, LSE_IN_LEVELMAJOR>(a, st);                                    \
+            case 32321: return FN<32, 32, 1, LSE_IN_LEVELMAJOR>(a, st);                                  \
+            default: break;                                                                              \
+            }                                                                                            \
+        } else {                                                                                         \
+            switch (key) {                                                                               \
+            case 16642: return FN<16, 64, 2, LSE_IN_ROWMAJOR>(a, st);                                    \
+            case 16641: return FN<16, 64, 1, LSE_IN_ROWMAJOR>(a, st);                                    \
+            case 16322: return FN<16, 32, 2, LSE_IN_ROWMAJOR>(a, st);                                    \
+            case 16321: return FN<16, 32, 1, LSE_IN_ROWMAJOR>(a, st);                                    \
+            case 32641: return FN<32, 64, 1, LSE_IN_ROWMAJOR>(a, st);                                    \
+            case 64642: return FN<64, 64, 2, LSE_IN_ROWMAJOR>(a, st);                                    \
+            default: break;                                                                              \
+            }                                                                                            \
+        }                                                                                                \
+        lse::set_error("mlp: no kernel instance for n_in=%d width=%d n_hidden_layers=%d in_layout=%d",   \
+                       (d)->n_in, (d)->width, (d)->n_hidden_layers, (d)->in_layout);                      \
+        return LSE_E_UNSUPPORTED;                                                                        \
+    } while (0)
+
+template <int M, int K, int AL>
+int launch_gemm_tn(const float *g, const float *a, int64_t n, float *dw, int dw_ld, hipStream_t st)
+{
+    const int64_t steps = (n + 3) / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((steps + 255) / 256, 1024));
+    hipLaunchKernelGGL((gemm_tn_kernel<M, K, AL>), dim3(blocks), dim3(256), 0, st, g, a, n, dw, dw_ld);
+    return lse::check_launch("lse_gemm_tn_acc");
+}
+
+int gemm_tn_dispatch(const float *g, int m, const float *a, int k, int al, int64_t n, float *dw, int dw_ld,
+                     hipStream_t st)
+{
+    if (n == 0) return LSE_OK;
+#define CASE(MM, KK, LL) \
+    if (m == MM && k == KK && al == LL) return launch_gemm_tn<MM, KK, LL>(g, a, n, dw, dw_ld, st)
+    CASE(64, 32, LSE_IN_LEVELMAJOR);
+    CASE(64, 8, LSE_IN_LEVELMAJOR);
+    CASE(32, 8, LSE_IN_LEVELMAJOR);
+    CASE(32, 32, LSE_IN_LEVELMAJOR);
+    CASE(64, 16, LSE_IN_ROWMAJOR);
+    CASE(64, 32, LSE_IN_ROWMAJOR);
+    CASE(64, 64, LSE_IN_ROWMAJOR);
+    CASE(32, 16, LSE_IN_ROWMAJOR);
+    CASE(32, 32, LSE_IN_ROWMAJOR);
+    CASE(16, 64, LSE_IN_ROWMAJOR);
+    CASE(16, 32, LSE_IN_ROWMAJOR);
+#undef CASE
+    lse::set_error("lse_gemm_tn_acc: no kernel instance for m=%d k=%d layout=%d", m, k, al);
+    return LSE_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
+                           const int32_t *row_bias_idx, float *out, float *act, int64_t n, lse_stream_t stream)
+{
+    int rc = check_desc(desc, "lse_mlp_fwd");
+    if (rc) return rc;
+    LSE_REQUIRE(n >= 0, "lse_mlp_fwd: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(params && in && out, "lse_mlp_fwd: null pointer");
+    MlpArgs a{};
+    a.params = params; a.in = in; a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.out = out; a.act = act;
+    a.n = n; a.out_activation = desc->out_activation;
+    hipStream_t st = lse::as_stream(stream);
+    LSE_MLP_DISPATCH(launch_fwd, desc, a, st);
+}
+
+extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *act, const float *out,
+                           const float *d_out, float *d_out_pre, float *d_act, float *d_in, int64_t n,
+                           lse_stream_t stream)
+{
+    int rc = check_desc(desc, "lse_mlp_bwd");
+    if (rc) return rc;
+    LSE_REQUIRE(n >= 0, "lse_mlp_bwd: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(params && act && d_out && d_out_pre && d_act, "lse_mlp_bwd: null pointer");
+    LSE_REQUIRE(desc->out_activation == LSE_ACT_NONE || out, "lse_mlp_bwd: sigmoid backward needs `out`");
+    MlpArgs a{};
+    a.params = params; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
+    a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_in = d_in; a.n = n; a.out_activation = desc->out_activation;
+    hipStream_t st = lse::as_stream(stream);
+    LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
+}
+
+extern "C" int lse_gemm_tn_acc(const float *g, int32_t m, const float *a, int32_t k, int32_t a_layout, int64_t n,
+                               float *dw, int32_t dw_ld, lse_stream_t stream)
+{
+    LSE_REQUIRE(n >= 0, "lse_gemm_tn_acc: n < 0");
+    LSE_REQUIRE(n == 0 || (g && a && dw), "lse_gemm_tn_acc: null pointer");
+    LSE_REQUIRE(dw_ld >= k, "lse_gemm_tn_acc: dw_ld < k");
+    return gemm_tn_dispatch(g, m, a, k, a_layout, n, dw, dw_ld, lse::as_stream(stream));
+}
+
+extern "C" int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
+                             const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream)
+{
+    int rc = check_desc(desc, "lse_mlp_wgrad");
+    if (rc) return rc;
+    LSE_REQUIRE(n >= 0, "lse_mlp_wgrad: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(in && act && d_act && d_out_pre && d_params, "lse_mlp_wgrad: null pointer");
+    hipStream_t st = lse::as_stream(stream);
+    const int W = desc->width, K0 = desc->n_in, NHL = desc->n_hidden_layers;
+    float *dW0 = d_params, *dW1 = dW0 + W * K0, *dWo = dW1 + (NHL - 1) * W * W;
+    rc = gemm_tn_dispatch(d_act, W, in, K0, desc->in_layout, n, dW0, K0, st);
+    if (rc) return rc;
+    if (NHL == 2) {
+        rc = gemm_tn_dispatch(d_act + n * W, W, act, W, LSE_IN_ROWMAJOR, n, dW1, W, st);
+        if (rc) return rc;
+    }
+    return gemm_tn_dispatch(d_out_pre, 16, act + (int64_t)(NHL - 1) * n * W, W, LSE_IN_ROWMAJOR, n, dWo, W, st);
+}
+
+extern "C" int lse_segment_sum_rows(const float *rows, int32_t width, const int64_t *packed_info, int32_t n_rays,
+                                    float *out, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0 && width >= 1 && width <= 64, "lse_segment_sum_rows: width must be in [1,64]");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(rows && packed_info && out, "lse_segment_sum_rows: null pointer");
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), rows,
+                       width, packed_info, n_rays, out);
+    return lse::check_launch("lse_segment_sum_rows");
+}
+
+extern "C" int lse_linear_fwd(const float *w, const float *x, int32_t rows, int32_t m, int32_t k, float *y,
+                              lse_stream_t stream)
+{
+    LSE_REQUIRE(rows >= 0 && m > 0 && k > 0, "lse_linear_fwd: bad shape");
+    if (rows == 0) return LSE_OK;
+    LSE_REQUIRE(w && x && y, "lse_linear_fwd: null pointer");
+    const int64_t tot = (int64_t)rows * m;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, lse::as_stream(stream), w, x,
+                       rows, m, k, y);
+    return lse::check_launch("lse_linear_fwd");
+}
+
+extern "C" int lse_linear_bwd_input(const float *w, const float *dy, int32_t rows, int32_t m, int32_t k, float *dx,
+                                    lse_stream_t stream)
+{
+    LSE_REQUIRE(rows >= 0 && m > 0 && k > 0, "lse_linear_bwd_input: bad shape");
+    if (rows == 0) return LSE_OK;
+    LSE_REQUIRE(w && dy && dx, "lse_linear_bwd_input: null pointer");
+    const int64_t tot = (int64_t)rows * k;
+    hipLaunchKernelGGL(linear_bwd_input_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       lse::as_stream(stream), w, dy, rows, m, k, dx);
+    return lse::check_launch("lse_linear_bwd_input");
+}

@@ -1,0 +1,120 @@
+// Flat-buffer Adam (torch.optim.Adam semantics, R:lse_nerf/lse_config.py:29-33: lr 1e-2, eps 1e-15) and the
+// occupancy-grid EMA update (nerfacc OccGridEstimator._update).  Pure HBM streams:
+// 16-byte vector accesses, grid capped at 2048 workgroups with a grid-stride loop.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float inv_sqrt_bc2,
+                                                   float gscale)
+{
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4 *>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4 *>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4 *>(v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gv[k] * gscale;
+            mv[k] = b1 * mv[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+            pv[k] -= step * (mv[k] / denom);
+        }
+        reinterpret_cast<f32x4 *>(p)[i] = pv;
+        reinterpret_cast<f32x4 *>(m)[i] = mv;
+        reinterpret_cast<f32x4 *>(v)[i] = vv;
+    }
+    // tail
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gk = g[t] * gscale;
+        const float mk = b1 * m[t] + (1.f - b1) * gk;
+        const float vk = b2 * v[t] + (1.f - b2) * gk * gk;
+        m[t] = mk;
+        v[t] = vk;
+        p[t] -= step * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+    }
+}
+
+// occs[id] = max(occs[id]*ema, occ_new) with duplicate ids resolved as the maximum over the duplicates:
+//   pass 1: ws[i] = max(occs[id_i]*ema, occ_i)      (reads only)
+//   pass 2: occs[id_i] = 0                           (benign same-value race)
+//   pass 3: atomic max (values are >= 0, so the int ordering equals the float ordering)
+__global__ void occ_pass1(const float *__restrict__ occs, const int64_t *__restrict__ ids, const float *__restrict__ nw,
+                          int64_t n, float ema, float *__restrict__ ws)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ws[i] = fmaxf(occs[ids[i]] * ema, nw[i]);
+}
+__global__ void occ_pass2(float *__restrict__ occs, const int64_t *__restrict__ ids, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) occs[ids[i]] = 0.f;
+}
+__global__ void occ_pass3(float *__restrict__ occs, const int64_t *__restrict__ ids, const float *__restrict__ ws,
+                          int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(reinterpret_cast<int *>(occs) + ids[i], __float_as_int(fmaxf(ws[i], 0.f)));
+}
+
+__global__ void occ_binarize_kernel(const float *__restrict__ occs, int64_t n, const float *__restrict__ thre,
+                                    uint8_t *__restrict__ bin)
+{
+    const float t = *thre;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bin[i] = occs[i] > t ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream)
+{
+    LSE_REQUIRE(n >= 0 && step >= 1, "lse_adam_step: need n >= 0 and step >= 1");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(params && grads && exp_avg && exp_avg_sq, "lse_adam_step: null pointer");
+    LSE_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "lse_adam_step: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t n4 = (n + 3) / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 2048));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
+                       n, lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    return lse::check_launch("lse_adam_step");
+}
+
+extern "C" int lse_occ_update_cells(float *occs, const int64_t *cell_ids, const float *occ_new, int64_t n,
+                                    float ema_decay, float *workspace, lse_stream_t stream)
+{
+    LSE_REQUIRE(n >= 0, "lse_occ_update_cells: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(occs && cell_ids && occ_new && workspace, "lse_occ_update_cells: null pointer");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipStream_t st = lse::as_stream(stream);
+    hipLaunchKernelGGL(occ_pass1, dim3(blocks), dim3(256), 0, st, occs, cell_ids, occ_new, n, ema_decay, workspace);
+    hipLaunchKernelGGL(occ_pass2, dim3(blocks), dim3(256), 0, st, occs, cell_ids, n);
+    hipLaunchKernelGGL(occ_pass3, dim3(blocks), dim3(256), 0, st, occs, cell_ids, workspace, n);
+    return lse::check_launch("lse_occ_update_cells");
+}
+
+extern "C" int lse_occ_binarize(const float *occs, int64_t n, const float *d_threshold, uint8_t *binaries,
+                                lse_stream_t stream)
+{
+    LSE_REQUIRE(n >= 0, "lse_occ_binarize: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(occs && d_threshold && binaries, "lse_occ_binarize: null pointer");
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(occ_binarize_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), occs, n, d_threshold,
+                       binaries);
+    return lse::check_launch("lse_occ_binarize");
+}

@@ -1,0 +1,235 @@
+// Packed per-ray transmittance scan + alpha compositing for gfx950, forward and backward:
+//   nerfacc.render_weight_from_density            R:lse_nerf/lsenerf.py:301-306
+//   nerfacc.render_visibility_from_density        R:lse_nerf/lse_grid_estimator.py:120-127
+//   RGB / accumulation / depth renderers          R:lse_nerf/lsenerf.py:309-318, R:lse_nerf/lse_renderer.py:6-10
+//
+// One 64-lane wave owns one ray: its samples are contiguous (packed, ray-sorted), so a chunk of 64 samples is
+// one coalesced load per stream, the exclusive sum of sigma*dt is a wave prefix scan with a scalar carry between
+// chunks, and the per-ray sums (rgb, accumulation, depth numerator) are wave reductions -- no atomics, no
+// index_add_, deterministic.  The backward is the same walk in reverse with suffix scans:
+//     dL/d(sd_k) = dw_k * T_{k+1} - sum_{i>k} dw_i w_i ,   T_{k+1} = T_end + sum_{i>k} w_i ,  T_end = 1 - sum_i w_i
+// (T_{k+1} = T_k - w_k exactly, so no transmittance array is stored and no cancellation-prone prefix is formed).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_inclusive_sum_rev(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float nb = __shfl_down(v, off, 64);
+        if (lse::lane_id() + off < 64) v += nb;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void volrend_fwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                          const float *__restrict__ sigma, const float *__restrict__ rgb,
+                                                          int rgb_stride, const int64_t *__restrict__ packed, int n_rays,
+                                                          float *__restrict__ weights, float *__restrict__ out_rgb,
+                                                          float *__restrict__ out_acc, float *__restrict__ out_dep)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f, ad = 0.f;
+    for (int64_t base = 0; base < cnt; base += 64) {
+        const int64_t i = s0 + base + lane;
+        const bool valid = base + lane < cnt;
+        float a = 0.f, b = 0.f, sg = 0.f;
+        if (valid) { a = ts[i]; b = te[i]; sg = sigma[i]; }
+        const float sd = sg * (b - a);
+        const float incl = lse::wave_inclusive_sum(sd);
+        const float excl = (incl - sd) + carry;
+        const float T = expf(-excl);
+        const float alpha = 1.f - expf(-sd);
+        const float w = valid ? T * alpha : 0.f;
+        if (valid) {
+            weights[i] = w;
+            if (rgb) {
+                const float *c = rgb + i * rgb_stride;
+                ar = fmaf(w, c[0], ar);
+                ag = fmaf(w, c[1], ag);
+                ab = fmaf(w, c[2], ab);
+            }
+            aw += w;
+            ad = fmaf(w, (a + b) * 0.5f, ad);
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+    ar = lse::wave_sum(ar); ag = lse::wave_sum(ag); ab = lse::wave_sum(ab);
+    aw = lse::wave_sum(aw); ad = lse::wave_sum(ad);
+    if (lane == 0) {
+        if (out_rgb) { out_rgb[ray * 3 + 0] = ar; out_rgb[ray * 3 + 1] = ag; out_rgb[ray * 3 + 2] = ab; }
+        if (out_acc) out_acc[ray] = aw;
+        if (out_dep) out_dep[ray] = ad;
+    }
+}
+
+__global__ __launch_bounds__(256) void volrend_bwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                          const float *__restrict__ sigma, const float *__restrict__ rgb,
+                                                          int rgb_stride, const int64_t *__restrict__ packed, int n_rays,
+                                                          const float *__restrict__ weights,
+                                                          const float *__restrict__ g_rgb, const float *__restrict__ g_acc,
+                                                          const float *__restrict__ g_dep, float *__restrict__ d_sigma,
+                                                          float *__restrict__ d_rgb)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    if (cnt == 0) return;
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float ga = g_acc ? g_acc[ray] : 0.f, gd = g_dep ? g_dep[ray] : 0.f;
+    float wtot = 0.f;
+    for (int64_t base = 0; base < cnt; base += 64)
+        if (base + lane < cnt) wtot += weights[s0 + base + lane];
+    wtot = lse::wave_sum(wtot);
+    const float t_end = 1.f - wtot;
+    float carry_w = 0.f, carry_g = 0.f;
+    const int64_t n_chunks = (cnt + 63) / 64;
+    for (int64_t ch = n_chunks - 1; ch >= 0; --ch) {
+        const int64_t base = ch * 64;
+        const int64_t i = s0 + base + lane;
+        const bool valid = base + lane < cnt;
+        float w = 0.f, dw = 0.f, dt = 0.f;
+        if (valid) {
+            w = weights[i];
+            const float a = ts[i], b = te[i];
+            dt = b - a;
+            dw = ga + gd * ((a + b) * 0.5f);
+            if (rgb && g_rgb) {
+                const float *c = rgb + i * rgb_stride;
+                dw += gr * c[0] + gg * c[1] + gb * c[2];
+            }
+        }
+        const float gw = dw * w;
+        const float incl_w = wave_inclusive_sum_rev(w);
+        const float incl_g = wave_inclusive_sum_rev(gw);
+        const float sw = (incl_w - w) + carry_w;     // sum_{i>k} w_i
+        const float sg = (incl_g - gw) + carry_g;    // sum_{i>k} dw_i w_i
+        if (valid) {
+            const float dsd = dw * (t_end + sw) - sg;
+            d_sigma[i] = dsd * dt;
+            if (d_rgb) {
+                float *dc = d_rgb + i * rgb_stride;
+                dc[0] = w * gr; dc[1] = w * gg; dc[2] = w * gb;
+            }
+        }
+        carry_w += __shfl(incl_w, 0, 64);
+        carry_g += __shfl(incl_g, 0, 64);
+    }
+}
+
+__global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                         const float *__restrict__ sigma,
+                                                         const int64_t *__restrict__ packed, int n_rays, float eps,
+                                                         float alpha_thre, uint8_t *__restrict__ mask,
+                                                         int64_t *__restrict__ new_cnts)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    float carry = 0.f;
+    int64_t kept = 0;
+    for (int64_t base = 0; base < cnt; base += 64) {
+        const int64_t i = s0 + base + lane;
+        const bool valid = base + lane < cnt;
+        float a = 0.f, b = 0.f, sg = 0.f;
+        if (valid) { a = ts[i]; b = te[i]; sg = sigma[i]; }
+        const float sd = sg * (b - a);
+        const float incl = lse::wave_inclusive_sum(sd);
+        const float T = expf(-((incl - sd) + carry));
+        const float alpha = 1.f - expf(-sd);
+        bool vis = valid && (T >= eps);
+        if (alpha_thre > 0.f) vis = vis && (alpha >= alpha_thre);
+        if (valid) mask[i] = vis ? 1 : 0;
+        kept += __popcll(__ballot(vis));
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0 && new_cnts) new_cnts[ray] = kept;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ mask, const int64_t *__restrict__ packed,
+                                                      const int64_t *__restrict__ new_packed, int n_rays,
+                                                      const int32_t *__restrict__ ri, const float *__restrict__ ts,
+                                                      const float *__restrict__ te, int32_t *__restrict__ o_ri,
+                                                      float *__restrict__ o_ts, float *__restrict__ o_te)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    int64_t dst = new_packed[2 * ray];
+    for (int64_t base = 0; base < cnt; base += 64) {
+        const int64_t i = s0 + base + lane;
+        const bool keep = (base + lane < cnt) && mask[i];
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            o_ri[dst + before] = ri[i];
+            o_ts[dst + before] = ts[i];
+            o_te[dst + before] = te[i];
+        }
+        dst += __popcll(bal);
+    }
+}
+
+}  // namespace
+
+extern "C" int lse_volrend_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                               int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, float *weights,
+                               float *out_rgb, float *out_acc, float *out_depth_num, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_volrend_fwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights, "lse_volrend_fwd: null pointer");
+    LSE_REQUIRE(!rgb || rgb_stride >= 3, "lse_volrend_fwd: rgb_stride < 3");
+    hipLaunchKernelGGL(volrend_fwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, rgb, rgb_stride, packed_info, n_rays, weights, out_rgb, out_acc, out_depth_num);
+    return lse::check_launch("lse_volrend_fwd");
+}
+
+extern "C" int lse_volrend_bwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                               int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, const float *weights,
+                               const float *d_out_rgb, const float *d_out_acc, const float *d_out_depth_num,
+                               float *d_sigmas, float *d_rgb, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_volrend_bwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights && d_sigmas, "lse_volrend_bwd: null pointer");
+    LSE_REQUIRE(!rgb || rgb_stride >= 3, "lse_volrend_bwd: rgb_stride < 3");
+    hipLaunchKernelGGL(volrend_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, rgb, rgb_stride, packed_info, n_rays, weights, d_out_rgb, d_out_acc, d_out_depth_num,
+                       d_sigmas, d_rgb);
+    return lse::check_launch("lse_volrend_bwd");
+}
+
+extern "C" int lse_visibility_mask(const float *t_starts, const float *t_ends, const float *sigmas,
+                                   const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
+                                   uint8_t *mask, int64_t *new_cnts, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_visibility_mask: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && mask, "lse_visibility_mask: null pointer");
+    hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts);
+    return lse::check_launch("lse_visibility_mask");
+}
+
+extern "C" int lse_compact_samples(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info,
+                                   int32_t n_rays, const int32_t *ray_indices, const float *t_starts,
+                                   const float *t_ends, int32_t *out_ray_indices, float *out_t_starts,
+                                   float *out_t_ends, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_compact_samples: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(mask && packed_info && new_packed_info && ray_indices && t_starts && t_ends && out_ray_indices &&
+                    out_t_starts && out_t_ends, "lse_compact_samples: null pointer");
+    hipLaunchKernelGGL(compact_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), mask, packed_info,
+                       new_packed_info, n_rays, ray_indices, t_starts, t_ends, out_ray_indices, out_t_starts, out_t_ends);
+    return lse::check_launch("lse_compact_samples");
+}

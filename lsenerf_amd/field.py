@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's field interface, running on the gfx950 kernels.
+
+Mirrors (same names, argument meaning, shapes, error behaviour):
+  * ``Ed_HashEncoding``                      R:lse_nerf/lse_field.py:43-91
+  * ``LSEField`` (get_density/get_outputs/forward/density_fn)   R:lse_nerf/lse_field.py:94-360
+  * ``EvsFrameEmbedding`` / ``GlobalEmbedding`` / ``LSEEmbeddingConfig``   R:lse_nerf/lse_embeddings.py:19-107
+nerfstudio itself is not importable here, so ``Field``/``MLP``/``SHEncoding`` are duck-typed.  Parameters use
+the tcnn layouts the reference trains with (``implementation="tcnn"``, R:lse_nerf/lsenerf.py:175); unlike the
+reference, the dead torch ``hash_table`` (R:lse_nerf/lse_field.py:63-65, 67 MB never used in tcnn mode) is not
+allocated.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from enum import Enum
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, ops
+from .rays import Frustums, RaySamples
+
+
+class FieldHeadNames(Enum):
+    RGB = "rgb"
+    DENSITY = "density"
+
+
+def _pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+# ----------------------------------------------------------------------------------------------------
+# encodings / MLP modules (parameter containers + single-op forwards)
+# ----------------------------------------------------------------------------------------------------
+class Ed_HashEncoding(nn.Module):
+    """tcnn HashGrid with the constructor signature of R:lse_nerf/lse_field.py:44-51.
+
+    ``forward(x[N,3] in [0,1]) -> [N, L*F]`` like tcnn's binding; ``forward_levelmajor`` returns the [L,N,F]
+    layout the fused MLP consumes without a transpose."""
+
+    def __init__(self, num_levels: int = 16, min_res: int = 16, max_res: int = 1024, log2_hashmap_size: int = 19,
+                 features_per_level: int = 2, hash_init_scale: float = 0.001, implementation: str = "hip",
+                 interpolation: Optional[str] = None) -> None:
+        super().__init__()
+        assert interpolation is None or interpolation == "Linear", \
+            f"interpolation '{interpolation}' is not supported for the hip encoding backend"
+        self.num_levels = num_levels
+        self.features_per_level = features_per_level
+        self.log2_hashmap_size = log2_hashmap_size
+        self.hash_table_size = 2 ** log2_hashmap_size
+        self.meta = ops.make_grid_meta(num_levels, features_per_level, log2_hashmap_size, min_res, max_res=max_res)
+        # tcnn grid init U(-1e-4, 1e-4) (hash_init_scale only applies to the torch table the reference leaves dead)
+        self.params = nn.Parameter((torch.rand(self.meta.n_params) * 2 - 1) * 1e-4)
+
+    def get_out_dim(self) -> int:
+        return self.num_levels * self.features_per_level
+
+    def forward_levelmajor(self, in_tensor: Tensor) -> Tensor:
+        return ops.hash_encode(in_tensor, self.params, self.meta)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        y = self.forward_levelmajor(in_tensor.reshape(-1, 3).contiguous())
+        n = y.shape[1]
+        return y.permute(1, 0, 2).reshape(n, -1).view(*in_tensor.shape[:-1], -1)
+
+
+class MLP(nn.Module):
+    """nerfstudio ``MLP(implementation="tcnn")``: bias-free, ReLU, tcnn flat ``params``."""
+
+    def __init__(self, in_dim: int, num_layers: int, layer_width: int, out_dim: int, activation=None,
+                 out_activation=None, implementation: str = "hip", in_layout: int = _lib.LSE_IN_ROWMAJOR) -> None:
+        super().__init__()
+        self.in_dim, self.out_dim, self.layer_width, self.num_layers = in_dim, out_dim, layer_width, num_layers
+        self.in_pad = _pad16(in_dim) if in_layout == _lib.LSE_IN_ROWMAJOR else in_dim
+        self.n_hidden_layers = num_layers - 1
+        assert out_dim <= 16, "the fused kernel pads outputs to 16"
+        self.out_act = _lib.LSE_ACT_SIGMOID if isinstance(out_activation, nn.Sigmoid) or out_activation == "Sigmoid" \
+            else _lib.LSE_ACT_NONE
+        self.in_layout = in_layout
+        shapes = [(layer_width, self.in_pad)] + [(layer_width, layer_width)] * (self.n_hidden_layers - 1) + [(16, layer_width)]
+        self.shapes = shapes
+        chunks = []
+        for (o, i) in shapes:   # tcnn xavier_uniform
+            s = math.sqrt(6.0 / (i + o))
+            chunks.append((torch.rand(o * i) * 2 - 1) * s)
+        self.params = nn.Parameter(torch.cat(chunks))
+
+    def get_out_dim(self) -> int:
+        return self.out_dim
+
+    def meta(self, n_in: Optional[int] = None) -> ops.MlpMeta:
+        return ops.MlpMeta(self.in_pad if n_in is None else n_in, self.layer_width, self.n_hidden_layers, self.out_act,
+                           self.in_layout)
+
+    def first_layer(self) -> Tensor:
+        return self.params[: self.layer_width * self.in_pad].view(self.layer_width, self.in_pad)
+
+    def rest(self) -> Tensor:
+        return self.params[self.layer_width * self.in_pad:]
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        """Generic path (any caller): row-major input, padded with ones like tcnn's Identity encoding."""
+        x = in_tensor.reshape(-1, in_tensor.shape[-1])
+        n = x.shape[0]
+        if self.in_layout == _lib.LSE_IN_ROWMAJOR and x.shape[-1] < self.in_pad:
+            x = torch.cat([x, torch.ones(n, self.in_pad - x.shape[-1], device=x.device, dtype=x.dtype)], dim=-1)
+        out = ops.fused_mlp(self.params, x.contiguous(), self.meta(), n)
+        return out[:, : self.out_dim].view(*in_tensor.shape[:-1], self.out_dim)
+
+
+# ----------------------------------------------------------------------------------------------------
+# embeddings (R:lse_nerf/lse_embeddings.py)
+# ----------------------------------------------------------------------------------------------------
+class Embedding(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int) -> None:
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.embedding = nn.Embedding(in_dim, out_dim)
+
+    def mean(self, dim=0):
+        return self.embedding.weight.mean(dim)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return self.embedding(in_tensor)
+
+
+class EvsFrameEmbedding(Embedding):
+    """R:lse_nerf/lse_embeddings.py:19-70 (per-frame appearance embedding indexed by metadata["appearance_id"])."""
+
+    def __init__(self, config, num_imgs, num_dims) -> None:
+        self.config = config
+        super().__init__(num_imgs, config.emb_dim)
+        self.test_emb = None
+
+    def ray_indices(self, ray_bundle_metadata: Dict[str, Tensor], camera_indices: Optional[Tensor], n_rays: int,
+                    device) -> Tensor:
+        return ray_bundle_metadata["appearance_id"].reshape(-1).to(torch.int32)
+
+    def forward(self, x: RaySamples, call_from_test=False):
+        idxs = x.metadata["appearance_id"]
+        return super().forward(idxs)
+
+    def get_test_emb(self, x: RaySamples):
+        mode = self.config.eval_mode
+        n = len(x)
+        dev = x.frustums.directions.device
+        if mode == "zero":
+            return torch.zeros((*x.frustums.directions.shape[:-1], self.out_dim), device=dev)
+        if mode == "mean":
+            return torch.ones((n, self.out_dim), device=dev) * self.mean(dim=0)
+        assert self.test_emb is not None, "for deblur pretrain test only! need to init test_emb!"
+        idxs = x.metadata["appearance_id"]
+        return self.test_emb(idxs * 0)
+
+    def init_test_params(self):
+        if self.test_emb is not None or (self.embedding.weight.shape[0] <= 1):
+            return
+        self.test_emb = nn.Embedding(1, self.out_dim).to(self.embedding.weight.device)
+        self.test_emb.weight = nn.Parameter(self.embedding(torch.tensor([21]).to(self.embedding.weight.device)))
+
+    def get_emb_dim(self):
+        return self.out_dim
+
+
+class GlobalEmbedding(EvsFrameEmbedding):
+    """R:lse_nerf/lse_embeddings.py:73-85: one row, index camera_indices*0."""
+
+    def __init__(self, config, num_imgs, num_dims) -> None:
+        super().__init__(config, 1, num_dims)
+
+    def ray_indices(self, ray_bundle_metadata, camera_indices, n_rays, device) -> Tensor:
+        return torch.zeros(n_rays, dtype=torch.int32, device=device)
+
+    def forward(self, x: RaySamples, call_from_test=False):
+        idxs = x.camera_indices * 0
+        return Embedding.forward(self, idxs)
+
+    def get_test_emb(self, x: RaySamples):
+        return self.forward(x)
+
+
+EMBEDDING_TYPE_DICT = {"global_emb": GlobalEmbedding, "evs_emb": EvsFrameEmbedding}
+
+
+@dataclass
+class LSEEmbeddingConfig:
+    """R:lse_nerf/lse_embeddings.py:94-107."""
+    embedding_type: str = "global_emb"
+    metadata: str = "dummy"
+    emb_dim: int = 32
+    eval_mode: str = "zero"
+
+    def setup(self, **kwargs):
+        return EMBEDDING_TYPE_DICT[self.embedding_type.lower()](self, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------------
+# the field
+# ----------------------------------------------------------------------------------------------------
+class LSEField(nn.Module):
+    """R:lse_nerf/lse_field.py:94-360 with the default-off heads (transient/semantics/normals) omitted.
+
+    ``spatial_distortion``: ``"inf"`` (nerfstudio ``SceneContraction(order=inf)``, what R:lse_nerf/lsenerf.py:166
+    builds) or ``None`` (aabb normalisation)."""
+
+    def __init__(self, aabb: Tensor, num_images: int, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15,
+                 num_levels: int = 16, base_res: int = 16, max_res: int = 2048, log2_hashmap_size: int = 19,
+                 num_layers_color: int = 3, features_per_level: int = 2, hidden_dim_color: int = 64,
+                 appearance_embedding_dim: int = 32, embd_config: Optional[LSEEmbeddingConfig] = None,
+                 spatial_distortion: Optional[str] = "inf", average_init_density: float = 1.0,
+                 implementation: str = "hip") -> None:
+        super().__init__()
+        assert geo_feat_dim == 15, "the fused head kernel assumes 1 + 15 base outputs"
+        assert spatial_distortion in ("inf", None)
+        self.register_buffer("aabb", aabb.float())
+        self.geo_feat_dim = geo_feat_dim
+        self.spatial_distortion = spatial_distortion
+        self.num_images = num_images
+        self.average_init_density = average_init_density
+        self.appearance_embedding_dim = appearance_embedding_dim
+        if self.appearance_embedding_dim > 0:
+            embd_config = embd_config or LSEEmbeddingConfig()
+            self.embedding_appearance = embd_config.setup(num_imgs=num_images, num_dims=appearance_embedding_dim)
+            self.appearance_embedding_dim = self.embedding_appearance.get_emb_dim()
+            assert self.appearance_embedding_dim == 32, "per-ray feature kernel packs a 32-wide embedding"
+        else:
+            self.embedding_appearance = None
+
+        self.mlp_base_grid = Ed_HashEncoding(num_levels=num_levels, min_res=base_res, max_res=max_res,
+                                             log2_hashmap_size=log2_hashmap_size, features_per_level=features_per_level)
+        self.mlp_base_mlp = MLP(in_dim=self.mlp_base_grid.get_out_dim(), num_layers=num_layers, layer_width=hidden_dim,
+                                out_dim=1 + geo_feat_dim, out_activation=None, in_layout=_lib.LSE_IN_LEVELMAJOR)
+        self.mlp_head = MLP(in_dim=16 + geo_feat_dim + self.appearance_embedding_dim, num_layers=num_layers_color,
+                            layer_width=hidden_dim_color, out_dim=3, out_activation="Sigmoid")
+        self._aabb6 = None
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _aabb_list(self):
+        if self._aabb6 is None:
+            self._aabb6 = [float(v) for v in self.aabb.flatten().tolist()]
+        return self._aabb6
+
+    def _x01(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info):
+        contraction = self.spatial_distortion == "inf"
+        return ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction,
+                             None if contraction else self._aabb_list())
+
+    def density_packed(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info
+                       ) -> Tuple[Tensor, Tensor, Tensor]:
+        """Fast path of get_density on packed samples: returns (sigma[N], h[N,16] base-MLP output, selector[N])."""
+        x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
+        n = x01.shape[0]
+        y = self.mlp_base_grid.forward_levelmajor(x01)
+        h = ops.fused_mlp(self.mlp_base_mlp.params, y, self.mlp_base_mlp.meta(), n)
+        sigma = ops.density_from_mlp_out(h, sel, self.average_init_density)
+        return sigma, h, sel
+
+    def _head_params_split(self):
+        """Split the tcnn head matrix W_in[width, 64|32] into the per-ray part (SH | emb | ones column) and the
+        per-sample part (geo columns, fed from the base output h[N,16] whose column 0 is the density logit)."""
+        head = self.mlp_head
+        W = head.layer_width
+        w_in = head.first_layer()                       # [W, in_pad]
+        zeros1 = torch.zeros(W, 1, device=w_in.device, dtype=w_in.dtype)
+        w_geo16 = torch.cat([zeros1, w_in[:, 16:16 + self.geo_feat_dim]], dim=1)      # [W,16]
+        if self.appearance_embedding_dim > 0:
+            w_ray = w_in                                                               # [W,64], geo slots meet zeros
+        else:
+            w_ray = torch.cat([w_in[:, :31], torch.zeros(W, 32, device=w_in.device, dtype=w_in.dtype),
+                               w_in[:, 31:32]], dim=1)
+        kernel_params = torch.cat([w_geo16.reshape(-1), head.rest()])
+        return w_ray, kernel_params
+
+    def rgb_packed(self, h: Tensor, rays_d: Tensor, emb_idx: Optional[Tensor], ray_idx: Optional[Tensor],
+                   packed_info: Optional[Tensor], emb_table: Optional[Tensor]) -> Tensor:
+        """Fast path of get_outputs: h[N,16] from ``density_packed``; per-ray directions/embedding ids.
+        Returns the padded head output [N,16] (columns 0..2 = RGB)."""
+        n = h.shape[0]
+        feat = ops.ray_features(rays_d, emb_table, emb_idx)                 # [R,64]
+        w_ray, kernel_params = self._head_params_split()
+        row_bias = ops.linear(feat, w_ray)                                   # [R,W]
+        meta = ops.MlpMeta(16, self.mlp_head.layer_width, self.mlp_head.n_hidden_layers, self.mlp_head.out_act,
+                           _lib.LSE_IN_ROWMAJOR)
+        return ops.fused_mlp(kernel_params, h, meta, n, row_bias, ray_idx, packed_info)
+
+    def _train_emb_table(self):
+        if self.embedding_appearance is None:
+            return None
+        return self.embedding_appearance.embedding.weight
+
+    def _eval_emb(self, n_rays: int, device):
+        """(table, idx) implementing get_test_emb for the per-ray feature kernel."""
+        emb = self.embedding_appearance
+        if emb is None:
+            return None, None
+        if isinstance(emb, GlobalEmbedding):
+            return emb.embedding.weight, torch.zeros(n_rays, dtype=torch.int32, device=device)
+        mode = emb.config.eval_mode
+        if mode == "zero":
+            return None, None
+        if mode == "mean":
+            return emb.mean(dim=0)[None, :].contiguous(), torch.zeros(n_rays, dtype=torch.int32, device=device)
+        assert emb.test_emb is not None, "for deblur pretrain test only! need to init test_emb!"
+        return emb.test_emb.weight, torch.zeros(n_rays, dtype=torch.int32, device=device)
+
+    # -- reference interface ---------------------------------------------------------------------------
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        """R:lse_nerf/lse_field.py:264-288 -> (density [N,1], geo features [N,15])."""
+        fr = ray_samples.frustums
+        if ray_samples.ray_indices is not None and ray_samples.ray_bundle is not None:
+            rb = ray_samples.ray_bundle
+            sigma, h, _ = self.density_packed(rb.origins, rb.directions, ray_samples.ray_indices,
+                                              fr.starts.reshape(-1), fr.ends.reshape(-1), ray_samples.packed_info)
+        else:
+            pos = fr.get_positions().reshape(-1, 3).contiguous()
+            sigma, h, _ = self.density_packed(pos, None, None, None, None, None)
+        geo = h[:, 1:1 + self.geo_feat_dim]
+        shape = fr.shape
+        if len(shape) != 1:
+            geo = geo.reshape(*shape, self.geo_feat_dim)
+        geo._lse_full = h      # lets get_outputs feed the head from the base output without a copy
+        return sigma.view(*shape, 1), geo
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> Dict[FieldHeadNames, Tensor]:
+        """R:lse_nerf/lse_field.py:290-360 -> {RGB: [N,3]}."""
+        assert density_embedding is not None
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        fr = ray_samples.frustums
+        n = len(ray_samples)
+        dev = fr.directions.device
+        h = getattr(density_embedding, "_lse_full", None)
+        if h is None:
+            h = torch.cat([torch.zeros(n, 1, device=dev), density_embedding.reshape(n, self.geo_feat_dim)], dim=1).contiguous()
+        if ray_samples.ray_indices is not None and ray_samples.ray_bundle is not None:
+            rb = ray_samples.ray_bundle
+            dirs, ridx, pinfo, n_rays = rb.directions, ray_samples.ray_indices, ray_samples.packed_info, len(rb)
+            meta, cams = rb.metadata, rb.camera_indices
+        else:   # arbitrary per-sample directions: every sample is its own "ray"
+            dirs, ridx, pinfo, n_rays = fr.directions.reshape(-1, 3).contiguous(), None, None, n
+            meta, cams = ray_samples.metadata, ray_samples.camera_indices
+        if self.embedding_appearance is None:
+            table, eidx = None, None
+        elif self.training:
+            table = self._train_emb_table()
+            eidx = self.embedding_appearance.ray_indices(meta, cams, n_rays, dev).contiguous()
+        else:
+            table, eidx = self._eval_emb(n_rays, dev)
+        out16 = self.rgb_packed(h, dirs, eidx, ridx, pinfo, table)
+        rgb = out16[:, :3].view(*fr.directions.shape[:-1], 3)
+        return {FieldHeadNames.RGB: rgb}
+
+    def density_fn(self, positions: Tensor) -> Tensor:
+        """nerfstudio ``Field.density_fn`` (wired at R:lse_nerf/lsenerf.py:193): positions [..,3] -> density [..,1]."""
+        p = positions.reshape(-1, 3).contiguous()
+        sigma, _, _ = self.density_packed(p, None, None, None, None, None)
+        return sigma.view(*positions.shape[:-1], 1)
+
+    def forward(self, ray_samples: RaySamples) -> Dict[FieldHeadNames, Tensor]:
+        """nerfstudio ``Field.forward``: get_density -> get_outputs -> add DENSITY."""
+        density, geo = self.get_density(ray_samples)
+        out = self.get_outputs(ray_samples, density_embedding=geo)
+        out[FieldHeadNames.DENSITY] = density
+        return out

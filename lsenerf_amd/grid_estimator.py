@@ -1,0 +1,153 @@
+"""Occupancy-grid estimator on the gfx950 kernels.
+
+``LSEOccGridEstimator.sampling`` mirrors R:lse_nerf/lse_grid_estimator.py:15-143 (argument names, defaults,
+assertion text, return order); the inherited nerfacc 0.5.2 ``OccGridEstimator`` surface (buffers ``resolution``,
+``aabbs``, ``occs``, ``binaries``; ``update_every_n_steps`` / ``_update``) is restated per SURVEY.md App. A.7.
+
+Differences from the reference, by design:
+  * the visibility pre-pass runs under no_grad (the reference builds a dead autograd graph, :14);
+  * ``ray_indices`` is int32 internally; ``sampling`` returns int64 like nerfacc unless ``return_packed`` is set;
+  * stratified jitter can be supplied by the caller (``jitter``) so that parity tests share the draw.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+
+def _enlarge_aabb(aabb: Tensor, factor: float) -> Tensor:
+    center = (aabb[:3] + aabb[3:]) / 2
+    extent = (aabb[3:] - aabb[:3]) / 2
+    return torch.cat([center - extent * factor, center + extent * factor])
+
+
+class LSEOccGridEstimator(nn.Module):
+    DIM: int = 3
+
+    def __init__(self, roi_aabb: Union[List[float], Tensor], resolution: Union[int, List[int], Tensor] = 128,
+                 levels: int = 1, **kwargs) -> None:
+        super().__init__()
+        if isinstance(resolution, int):
+            resolution = [resolution] * self.DIM
+        if isinstance(resolution, (list, tuple)):
+            resolution = torch.tensor(resolution, dtype=torch.int32)
+        if isinstance(roi_aabb, (list, tuple)):
+            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
+        assert roi_aabb.numel() == 6
+        roi_aabb = roi_aabb.detach().flatten().float()
+        aabbs = torch.stack([_enlarge_aabb(roi_aabb, 2 ** i) for i in range(levels)], dim=0)
+        self.cells_per_lvl = int(resolution.prod().item())
+        self.levels = levels
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("aabbs", aabbs)
+        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
+        r = resolution.tolist()
+        grid_coords = torch.stack(torch.meshgrid([torch.arange(k) for k in r], indexing="ij"), dim=-1).reshape(-1, 3)
+        self.register_buffer("grid_coords", grid_coords, persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        self._occ_mean_host: Optional[float] = None   # cached occs.mean() (refreshed by _update), saves a sync per forward
+
+    # ---------------------------------------------------------------------------------------------
+    def _binaries_u8(self) -> Tensor:
+        return self.binaries.view(torch.uint8)
+
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
+                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
+                 t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                 early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False):
+        """Sampling with spatial skipping (not differentiable).  Returns (ray_indices, t_starts, t_ends); with
+        ``return_packed`` also ``packed_info`` and ray_indices stays int32."""
+        if alpha_fn is not None:
+            raise NotImplementedError("alpha_fn is not on the LSENeRF path (VolumetricSampler passes sigma_fn)")
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if t_max is not None:
+            far_planes = torch.clamp(far_planes, max=t_max)
+        if stratified:
+            u = jitter if jitter is not None else torch.rand_like(near_planes)
+            near_planes = near_planes + u * render_step_size
+        ray_indices, t_starts, t_ends, packed_info = ops.traverse_grids(
+            rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes.contiguous(),
+            far_planes.contiguous(), render_step_size, cone_angle)
+
+        # skip invisible space
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None):
+            if self._occ_mean_host is None:
+                self._occ_mean_host = self.occs.mean().item()
+            alpha_thre = min(alpha_thre, self._occ_mean_host)
+            with torch.no_grad():
+                sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+            assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+            ray_indices, t_starts, t_ends, packed_info, _ = ops.visibility_compact(
+                ray_indices, t_starts, t_ends, sigmas.contiguous(), packed_info, early_stop_eps, alpha_thre)
+        if return_packed:
+            return ray_indices, t_starts, t_ends, packed_info
+        return ray_indices.long(), t_starts, t_ends
+
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16, generator: Optional[torch.Generator] = None) -> None:
+        if not self.training:
+            raise RuntimeError("You should only call this function only during training. "
+                               "Please call _update() directly if you want to update the field during inference.")
+        if step % n == 0 and self.training:
+            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
+                         warmup_steps=warmup_steps, generator=generator)
+
+    @torch.no_grad()
+    def _get_all_cells(self) -> List[Tensor]:
+        return [self.grid_indices[self.occs[l * self.cells_per_lvl:(l + 1) * self.cells_per_lvl] >= 0.0]
+                for l in range(self.levels)]
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int, generator=None) -> List[Tensor]:
+        out = []
+        dev = self.occs.device
+        for l in range(self.levels):
+            uniform = torch.randint(self.cells_per_lvl, (n,), device=dev, generator=generator)
+            lvl_occ = self.occs[l * self.cells_per_lvl + uniform]
+            uniform = uniform[lvl_occ >= 0.0]
+            occupied = torch.nonzero(self.binaries[l].flatten())[:, 0]
+            if n < len(occupied):
+                sel = torch.randint(len(occupied), (n,), device=dev, generator=generator)
+                occupied = occupied[sel]
+            out.append(torch.cat([uniform, occupied], dim=0))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256, generator: Optional[torch.Generator] = None) -> None:
+        """nerfacc ``OccGridEstimator._update``.  Index generation is torch plumbing; the EMA-max and the
+        binarisation run in the HIP kernels (lse_occ_update_cells / lse_occ_binarize)."""
+        if step < warmup_steps:
+            lvl_indices = self._get_all_cells()
+        else:
+            lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4, generator)
+        dev = self.occs.device
+        for lvl, indices in enumerate(lvl_indices):
+            grid_coords = self.grid_coords[indices]
+            u = torch.rand(grid_coords.shape, dtype=torch.float32, device=dev, generator=generator)
+            x = (grid_coords + u) / self.resolution
+            ab = self.aabbs[lvl]
+            x = ab[:3] + x * (ab[3:] - ab[:3])
+            occ = occ_eval_fn(x).squeeze(-1)
+            cell_ids = (lvl * self.cells_per_lvl + indices).contiguous()
+            ops.occ_update_cells(self.occs, cell_ids, occ.contiguous().float(), ema_decay)
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre).reshape(1).contiguous()
+        ops.occ_binarize(self.occs, thre, self._binaries_u8().view(-1))
+        self._occ_mean_host = None
+
+    def mark_all_occupied(self, value: float = 1.0) -> None:
+        """Benchmark helper: the 'grid fully occupied' regime of training steps < 256."""
+        self.occs.fill_(value)
+        self.binaries.fill_(True)
+        self._occ_mean_host = None

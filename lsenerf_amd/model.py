@@ -1,0 +1,370 @@
+"""``LSENeRFModel`` -- the hot-path driver with the reference's model interface.
+
+Mirrors R:lse_nerf/lsenerf.py: ``LSENeRFModelConfig`` (:47-99, plus the nerfstudio ``InstantNGPModelConfig``
+defaults the reference inherits), ``populate_modules`` (:158-228), ``forward`` (:265-276),
+``exec_get_outputs`` (:278-326), ``get_outputs`` (:329-377), ``get_param_groups`` (:231-249) and the losses
+(:392-439).  nerfstudio's ``VolumetricSampler`` is restated as a small module.
+
+The fast path keeps samples packed: one sampler call, one field pass, ONE volume-rendering kernel that yields
+weights, rgb, accumulation and the depth numerator (the reference composes pack_info + render_weight_from_density
++ three index_add_ renderers).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import ops
+from .field import FieldHeadNames, LSEEmbeddingConfig, LSEField
+from .grid_estimator import LSEOccGridEstimator
+from .rays import Frustums, RayBundle, RaySamples
+from .renderer import AccumulationRenderer, DepthRenderer, LinearRenderer, RGBRenderer, finish_depth
+
+EPS = 1e-6   # R:lse_nerf/utils.py:12
+
+
+@dataclass
+class LSENeRFModelConfig:
+    # --- InstantNGPModelConfig defaults inherited at R:lse_nerf/lsenerf.py:48
+    grid_resolution: int = 128
+    grid_levels: int = 4
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    alpha_thre: float = 0.01
+    cone_angle: float = 0.004
+    render_step_size: Optional[float] = None
+    near_plane: float = 0.05
+    far_plane: float = 1e3
+    background_color: str = "random"
+    disable_scene_contraction: bool = False
+    eval_num_rays_per_chunk: int = 3512          # R:lse_nerf/lse_config.py:27
+    # --- R:lse_nerf/lsenerf.py:50-84
+    evs_loss_weight: float = 1.0
+    emb_norm_weight: float = 1e-2
+    event_loss_type: str = "log_loss"
+    use_mapping: bool = False
+    mapping_method: str = "identity"
+    evs_mapping_method: Optional[str] = None
+    ev_one_dim: object = "learned"
+    rgb_loss_type: str = "linspace"
+    map_mode: str = "evs_rgb"
+    embed_config: LSEEmbeddingConfig = field(default_factory=LSEEmbeddingConfig)
+    # --- field size knobs (BASELINE config 1 uses L=4, 2x32)
+    num_levels: int = 16
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+
+    def __post_init__(self):   # R:lse_nerf/lsenerf.py:86-99
+        if self.evs_mapping_method is None or str(self.evs_mapping_method).lower() == "none":
+            self.evs_mapping_method = None
+        if self.map_mode.lower() == "none":
+            self.map_mode = "evs_rgb"
+        if isinstance(self.ev_one_dim, str):
+            if self.ev_one_dim.lower() in ("false", "none"):
+                self.ev_one_dim = False
+            elif self.ev_one_dim.lower() == "true":
+                self.ev_one_dim = "learned"
+        if self.rgb_loss_type.lower() == "none":
+            self.rgb_loss_type = "linspace"
+
+
+class ThreeToOne(nn.Module):
+    """R:lse_nerf/lsenerf.py:102-109."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.weights = nn.Parameter(torch.ones(1, 3) / 3)
+
+    def forward(self, x):
+        return F.linear(x, F.softmax(self.weights, dim=-1), None)
+
+
+class ToGrayGT(nn.Module):
+    """R:lse_nerf/lsenerf.py:112-119."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.register_buffer("c2g_vec", torch.tensor([0.2989, 0.5870, 0.1140]).reshape(-1, 1))
+
+    def forward(self, img):
+        return img @ self.c2g_vec
+
+
+class IdentityMapper(nn.Module):
+    def forward(self, x, **kwargs):
+        return x
+
+
+class GT_Mapper(nn.Module):
+    def forward(self, x, **kwargs):
+        return x ** (1 / 2.4)
+
+
+class Powpow(nn.Module):
+    """R:lse_nerf/intensity_mappers.py:84-90."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.pow_coeff = nn.Parameter(torch.tensor([1.0], dtype=torch.float32))
+
+    def forward(self, x, **kwargs):
+        return x ** self.pow_coeff
+
+
+MAPPERS_DICT = {"gt": GT_Mapper, "identity": IdentityMapper, "powpow": Powpow}   # R:lse_nerf/intensity_mappers.py:89-94
+format_linear = lambda x: torch.concatenate([x] * 3, dim=-1) if x.shape[-1] == 1 else x
+
+
+def to_gray(x: Tensor) -> Tensor:
+    return (x * x.new_tensor([0.2989, 0.5870, 0.1140])).sum(-1, keepdim=True)
+
+
+class VolumetricSampler(nn.Module):
+    """nerfstudio 0.3.2 ``VolumetricSampler`` (constructed at R:lse_nerf/lsenerf.py:191-194)."""
+
+    def __init__(self, occupancy_grid: LSEOccGridEstimator, density_fn: Optional[Callable] = None):
+        super().__init__()
+        assert occupancy_grid is not None
+        self.density_fn = density_fn
+        self.occupancy_grid = occupancy_grid
+
+    def get_sigma_fn(self, origins, directions) -> Optional[Callable]:
+        if self.density_fn is None or not self.training:
+            return None
+        density_fn = self.density_fn
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            return density_fn(origins, directions, ray_indices, t_starts, t_ends)
+        return sigma_fn
+
+    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
+                alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None
+                ) -> Tuple[RaySamples, Tensor]:
+        rays_o = ray_bundle.origins.contiguous()
+        rays_d = ray_bundle.directions.contiguous()
+        t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None else None
+        t_max = ray_bundle.fars.contiguous().reshape(-1) if ray_bundle.fars is not None else None
+        if far_plane is None:
+            far_plane = 1e10
+        camera_indices = ray_bundle.camera_indices
+        ray_indices, starts, ends, packed_info = self.occupancy_grid.sampling(
+            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max, sigma_fn=self.get_sigma_fn(rays_o, rays_d),
+            render_step_size=render_step_size, near_plane=near_plane, far_plane=far_plane, stratified=self.training,
+            cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, return_packed=True)
+        num_samples = starts.shape[0]
+        if num_samples == 0:   # create a single fake sample (nerfstudio) and update packed_info accordingly
+            dev = rays_o.device
+            ray_indices = torch.zeros((1,), dtype=torch.int32, device=dev)
+            starts = torch.ones((1,), dtype=starts.dtype, device=dev)
+            ends = torch.ones((1,), dtype=ends.dtype, device=dev)
+            packed_info = torch.zeros((rays_o.shape[0], 2), dtype=torch.int64, device=dev)
+            packed_info[0, 1] = 1
+        li = ray_indices.long()
+        ray_samples = RaySamples(
+            frustums=Frustums(origins=rays_o[li], directions=rays_d[li], starts=starts[..., None], ends=ends[..., None],
+                              pixel_area=ray_bundle.pixel_area[li] if ray_bundle.pixel_area is not None else None),
+            camera_indices=camera_indices[li] if camera_indices is not None else None,
+            ray_indices=ray_indices, packed_info=packed_info, ray_bundle=ray_bundle)
+        if ray_bundle.times is not None:
+            ray_samples.times = ray_bundle.times[li]
+        return ray_samples, li
+
+
+class LSENeRFModel(nn.Module):
+    """R:lse_nerf/lsenerf.py:141-439 (NGPModel subclass upstream)."""
+
+    def __init__(self, config: LSENeRFModelConfig, scene_aabb: Tensor, num_train_data: int, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.scene_aabb_2x3 = scene_aabb.float().reshape(2, 3)
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        self.collider = None                       # enable_collider False for NGP
+        self.populate_modules()
+        self.log_losses_dict = {"log_loss": self.log_loss, "enerf_norm_loss": self.enerf_norm_loss}
+        self.rgb_losses_dic = {"linspace": self.mse_loss, "deblur": self.mse_loss}
+        self.rgb_loss_fn = self.rgb_losses_dic[self.config.rgb_loss_type.lower()]
+        self.event_loss = self.log_losses_dict[self.config.event_loss_type.lower()]
+
+    # -- R:lse_nerf/lsenerf.py:158-228 ----------------------------------------------------------------
+    def populate_modules(self):
+        cfg = self.config
+        self.field = LSEField(aabb=self.scene_aabb_2x3, num_images=self.num_train_data,
+                              log2_hashmap_size=cfg.log2_hashmap_size, max_res=cfg.max_res,
+                              spatial_distortion=None if cfg.disable_scene_contraction else "inf",
+                              embd_config=cfg.embed_config, num_levels=cfg.num_levels, hidden_dim=cfg.hidden_dim,
+                              hidden_dim_color=cfg.hidden_dim_color)
+        self.scene_aabb = nn.Parameter(self.scene_aabb_2x3.flatten(), requires_grad=False)
+        if cfg.render_step_size is None:   # auto step size: ~1000 samples in the base level grid
+            cfg.render_step_size = ((self.scene_aabb[3:] - self.scene_aabb[:3]) ** 2).sum().sqrt().item() / 1000
+        self.occupancy_grid = LSEOccGridEstimator(roi_aabb=self.scene_aabb.data, resolution=cfg.grid_resolution,
+                                                  levels=cfg.grid_levels)
+        self.sampler = VolumetricSampler(occupancy_grid=self.occupancy_grid, density_fn=self._packed_density_fn)
+        self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="expected")
+        self.rgb_loss = nn.MSELoss()
+        if cfg.use_mapping:
+            init = MAPPERS_DICT.get(cfg.mapping_method.lower())
+            assert init is not None, f"{cfg.mapping_method} mapper is not supported"
+            self.rgb_mapper = init()
+            self.renderer_rgb = LinearRenderer(background_color=cfg.background_color)
+        self.evs_mapper = None
+        if cfg.evs_mapping_method is not None and cfg.map_mode == "co_map":
+            init = MAPPERS_DICT.get(cfg.evs_mapping_method.lower())
+            assert init is not None, f"{cfg.evs_mapping_method} mapper is not supported"
+            self.evs_mapper = init()
+        if cfg.ev_one_dim == "learned":
+            self.rgb_to_one = ThreeToOne()
+        elif cfg.ev_one_dim == "gt":
+            self.rgb_to_one = ToGrayGT()
+
+    def _packed_density_fn(self, origins, directions, ray_indices, t_starts, t_ends) -> Tensor:
+        """sigma_fn of nerfstudio's VolumetricSampler: positions at the interval mid-points -> field.density_fn.
+        Evaluated on packed samples without materialising the [N,3] gathers."""
+        sigma, _, _ = self.field.density_packed(origins, directions, ray_indices, t_starts, t_ends, None)
+        return sigma
+
+    def get_training_callbacks(self):
+        """NGPModel.get_training_callbacks: occupancy refresh before every train iteration."""
+        def update_occupancy_grid(step: int):
+            self.occupancy_grid.update_every_n_steps(
+                step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
+        return [update_occupancy_grid]
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """R:lse_nerf/lsenerf.py:231-249 (NGPModel: {"fields": field parameters})."""
+        groups = {"fields": list(self.field.parameters())}
+        if self.config.mapping_method == "gt":
+            return groups
+        if self.config.use_mapping:
+            groups["fields"] += list(self.rgb_mapper.parameters())
+        if self.config.ev_one_dim:
+            groups["fields"] += list(self.rgb_to_one.parameters())
+        if self.config.evs_mapping_method is not None and self.evs_mapper is not None:
+            groups["fields"] += list(self.evs_mapper.parameters())
+        return groups
+
+    def correct_evs_dim(self, inp):
+        return self.rgb_to_one(inp) if self.config.ev_one_dim else inp
+
+    # -- R:lse_nerf/lsenerf.py:265-326 ----------------------------------------------------------------
+    def forward(self, ray_bundle: RayBundle, **kwargs):
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle, **kwargs)
+
+    def exec_get_outputs(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None):
+        assert self.field is not None
+        num_rays = len(ray_bundle)
+        cfg = self.config
+        ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=cfg.near_plane,
+                                                far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
+                                                alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter)
+        # the per-sample metadata gathers of R:lse_nerf/lsenerf.py:292-296 are skipped: appearance ids stay per ray
+        return self.render_packed(ray_bundle, ray_samples.ray_indices, ray_samples.frustums.starts[..., 0],
+                                  ray_samples.frustums.ends[..., 0], ray_samples.packed_info)
+
+    def render_packed(self, ray_bundle: RayBundle, ray_idx: Tensor, t_starts: Tensor, t_ends: Tensor,
+                      packed_info: Tensor) -> Dict[str, Tensor]:
+        """R:lse_nerf/lsenerf.py:297-326 on packed samples: field -> weights -> rgb / depth / accumulation."""
+        num_rays = len(ray_bundle)
+        fld = self.field
+        rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        sigma, h, _ = fld.density_packed(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
+        if fld.embedding_appearance is None:
+            table, eidx = None, None
+        elif fld.training:
+            table = fld._train_emb_table()
+            eidx = fld.embedding_appearance.ray_indices(ray_bundle.metadata, ray_bundle.camera_indices, num_rays,
+                                                        rays_o.device).contiguous()
+        else:
+            table, eidx = fld._eval_emb(num_rays, rays_o.device)
+        rgb16 = fld.rgb_packed(h, rays_d, eidx, ray_idx, packed_info, table)
+        linear = isinstance(self.renderer_rgb, LinearRenderer)
+        if not (self.training or linear):
+            rgb16 = torch.nan_to_num(rgb16)
+        rgb, acc, depth_num, weights = ops.volume_render(t_starts, t_ends, sigma, rgb16, packed_info)
+        bg = self.config.background_color
+        if bg not in ("random", "last_sample"):
+            rgb = rgb + {"black": 0.0, "white": 1.0}[bg] * (1.0 - acc[:, None])
+        if not (self.training or linear):
+            rgb = torch.clamp(rgb, 0.0, 1.0)
+        depth = finish_depth(depth_num, acc, t_starts, t_ends)
+        return {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None],
+                "num_samples_per_ray": packed_info[:, 1]}
+
+    # -- R:lse_nerf/lsenerf.py:329-377 ----------------------------------------------------------------
+    def get_outputs(self, ray_bundle: RayBundle, ev_out=False, jitter: Optional[Tensor] = None, **kwargs):
+        out_dict = self.exec_get_outputs(ray_bundle, jitter=jitter)
+        cfg = self.config
+        clamp_out = torch.clamp(out_dict["rgb"], 1e-5)
+        if cfg.use_mapping or cfg.map_mode == "rgb_evs":
+            if cfg.map_mode == "rgb_evs":
+                if ev_out or not self.training:
+                    out_dict["ev_out"] = self.rgb_mapper(self.correct_evs_dim(clamp_out))
+                    out_dict["linear"] = format_linear(out_dict["ev_out"])
+            elif cfg.map_mode == "evs_rgb":
+                out_dict["ev_out"] = self.correct_evs_dim(clamp_out)
+                out_dict["linear"] = clamp_out
+                out_dict["rgb"] = self.rgb_mapper(out_dict["linear"]).to(out_dict["linear"])
+            elif cfg.map_mode == "co_map":
+                out_dict["rgb"] = self.rgb_mapper(clamp_out)
+                if ev_out or not self.training:
+                    ev_linear = self.correct_evs_dim(clamp_out)
+                    out_dict["linear"] = clamp_out
+                    out_dict["ev_linear"] = ev_linear
+                    out_dict["ev_out"] = self.evs_mapper(ev_linear, raybd1=ray_bundle, **kwargs)
+        if cfg.rgb_loss_type == "deblur" and self.training:
+            try:
+                out_dict["rgb"] = out_dict["rgb"].reshape(-1, 4, 3).mean(axis=1)
+            except Exception:
+                pass
+        if not self.training:
+            out_dict["rgb"] = torch.clamp(out_dict["rgb"], 0, 1)
+        else:
+            out_dict["rgb"] = torch.clamp(out_dict["rgb"], 1e-5)
+        return out_dict
+
+    # -- losses, R:lse_nerf/lsenerf.py:392-439 ---------------------------------------------------------
+    def log_loss(self, evs, prev_rad, next_rad, evs_batch: dict):
+        if prev_rad.shape[-1] != 1:
+            prev_rad, next_rad = to_gray(prev_rad), to_gray(next_rad)
+        prev_log, next_log = torch.log(prev_rad + EPS), torch.log(next_rad + EPS)
+        return self.rgb_loss(next_log - prev_log, evs)
+
+    def mse_loss(self, rgb_gt, rgb_pred, rgb_out_dic=None):
+        return self.rgb_loss(rgb_gt, rgb_pred)
+
+    def enerf_norm_loss(self, evs, prev_rad, next_rad, evs_batch: dict):
+        if prev_rad.shape[-1] != 1:
+            prev_rad, next_rad = to_gray(prev_rad), to_gray(next_rad)
+        prev_log, next_log = torch.log(prev_rad + EPS), torch.log(next_rad + EPS)
+        delta_log = next_log - prev_log
+        log_norm_cnst = torch.linalg.norm(delta_log, dim=0, keepdim=True) + EPS
+        with torch.no_grad():
+            evs = evs / evs_batch["e_thresh"]
+            evs_norm_cnst = torch.linalg.norm(evs, dim=0, keepdim=True) + EPS
+        return self.rgb_loss(delta_log / log_norm_cnst, evs / evs_norm_cnst)
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        loss_dict = {}
+        if (batch.get("col_batch") is None) and (batch.get("evs_batch") is None):
+            loss_dict["rgb_loss"] = self.rgb_loss(batch["image"], outputs["rgb"])
+            return loss_dict
+        col_batch, evs_batch = batch["col_batch"], batch["evs_batch"]
+        col_out, prev_out, next_out = [outputs[e] for e in ["col_out", "prev_out", "next_out"]]
+        if col_out is not None:
+            loss_dict["rgb_loss"] = self.rgb_loss_fn(col_batch["image"], col_out["rgb"], col_out)
+        if prev_out is not None:
+            ev_key = "rgb" if not self.config.use_mapping else "ev_out"
+            prev_in, next_in = prev_out[ev_key], next_out[ev_key]
+            evs = evs_batch["image"]
+            evs = evs if prev_in.shape[-1] == 1 else torch.concatenate([evs] * 3, dim=-1)
+            loss_dict["event_loss"] = self.config.evs_loss_weight * self.event_loss(evs, prev_in, next_in, evs_batch)
+        return loss_dict

@@ -1,0 +1,498 @@
+"""Torch-facing custom ops over the C-ABI (include/lse_hip.h): tensor checks, workspace allocation, autograd.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every op below launches the
+hand-written gfx950 kernels on torch's current HIP stream.  No CPU implementation exists on this path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import ctypes
+import torch
+
+from . import _lib
+from ._lib import GridDesc, MlpDesc
+
+
+# ----------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f"{name} is None")
+    if not t.is_cuda:
+        raise _lib.LseHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, name, allow_none=False):
+    return _chk(t, torch.float32, name, allow_none)
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------
+# descriptors
+# ----------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class GridMeta:
+    """tcnn HashGrid level table (host side).  Same arithmetic as tcnn's GridEncoding constructor; the oracle's
+    ``tcnn_grid_meta`` is an independent restatement used by the tests to cross-check these numbers."""
+    n_levels: int
+    n_features: int
+    log2_hashmap_size: int
+    base_resolution: int
+    per_level_scale: float
+    scales: Tuple[float, ...]
+    resolutions: Tuple[int, ...]
+    offsets: Tuple[int, ...]
+
+    @property
+    def n_entries(self):
+        return self.offsets[-1]
+
+    @property
+    def n_params(self):
+        return self.offsets[-1] * self.n_features
+
+    def desc(self) -> GridDesc:
+        d = GridDesc()
+        d.n_levels, d.n_features = self.n_levels, self.n_features
+        for i, o in enumerate(self.offsets):
+            d.offsets[i] = o
+        for i in range(self.n_levels):
+            d.scales[i] = self.scales[i]
+            d.resolutions[i] = self.resolutions[i]
+        return d
+
+
+def make_grid_meta(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=None,
+                   max_res=2048) -> GridMeta:
+    import numpy as np
+    if per_level_scale is None:   # R:lse_nerf/lse_field.py:59
+        per_level_scale = float(np.exp((np.log(max_res) - np.log(base_resolution)) / (n_levels - 1))) if n_levels > 1 else 1.0
+    pls = np.float32(per_level_scale)
+    l2 = np.log2(pls, dtype=np.float32)
+    scales, ress, offs = [], [], [0]
+    for l in range(n_levels):
+        s = np.float32(np.exp2(np.float32(l) * l2, dtype=np.float32) * np.float32(base_resolution) - np.float32(1))
+        r = int(np.ceil(s)) + 1
+        n = min(r ** 3, (2 ** 32 - 1) // 2)
+        n = (n + 7) // 8 * 8
+        n = min(n, 1 << log2_hashmap_size)
+        scales.append(float(s)); ress.append(r); offs.append(offs[-1] + n)
+    return GridMeta(n_levels, n_features, log2_hashmap_size, base_resolution, float(pls), tuple(scales), tuple(ress),
+                    tuple(offs))
+
+
+@dataclass(frozen=True)
+class MlpMeta:
+    n_in: int                 # padded input width seen by the kernel (8/16/32/64)
+    width: int
+    n_hidden_layers: int
+    out_activation: int = _lib.LSE_ACT_NONE
+    in_layout: int = _lib.LSE_IN_ROWMAJOR
+
+    @property
+    def n_params(self):
+        return self.width * self.n_in + (self.n_hidden_layers - 1) * self.width * self.width + 16 * self.width
+
+    def desc(self) -> MlpDesc:
+        return MlpDesc(self.n_in, self.width, self.n_hidden_layers, self.out_activation, self.in_layout)
+
+
+# ----------------------------------------------------------------------------------------------------
+# sampler
+# ----------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float):
+    """nerfacc.grid.traverse_grids as consumed at R:lse_nerf/lse_grid_estimator.py:93-106.
+    Returns (ray_indices int32 [N], t_starts [N], t_ends [N], packed_info int64 [R,2]).  One host sync (N)."""
+    R = rays_o.shape[0]
+    L, rx, ry, rz = binaries.shape
+    dev = rays_o.device
+    cnts = torch.empty(R, dtype=torch.int64, device=dev)
+    packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    args = (_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), R, _chk(binaries, torch.uint8, "binaries"),
+            _f32(aabbs, "aabbs"), L, rx, ry, rz, _f32(near_planes, "near_planes"), _f32(far_planes, "far_planes"),
+            float(step_size), float(cone_angle))
+    _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, _stream())
+    _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
+              ctypes.c_void_p(total.data_ptr()), _stream())
+    n = int(total.item())
+    ri = torch.empty(n, dtype=torch.int32, device=dev)
+    ts = torch.empty(n, dtype=torch.float32, device=dev)
+    te = torch.empty(n, dtype=torch.float32, device=dev)
+    if n > 0:
+        starts = packed[:, 0].contiguous()
+        _lib.call("lse_traverse_grids", *args, 1, None, ctypes.c_void_p(starts.data_ptr()),
+                  ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(te.data_ptr()),
+                  _stream())
+    return ri, ts, te, packed
+
+
+@torch.no_grad()
+def pack_info_from_counts(cnts: torch.Tensor):
+    R = cnts.shape[0]
+    packed = torch.empty((R, 2), dtype=torch.int64, device=cnts.device)
+    total = torch.zeros(1, dtype=torch.int64, device=cnts.device)
+    _lib.call("lse_pack_info_from_counts", _chk(cnts, torch.int64, "cnts"), R, ctypes.c_void_p(packed.data_ptr()),
+              ctypes.c_void_p(total.data_ptr()), _stream())
+    return packed, total
+
+
+@torch.no_grad()
+def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float):
+    """render_visibility_from_density + mask compaction (R:lse_nerf/lse_grid_estimator.py:120-143)."""
+    R = packed_info.shape[0]
+    n = t_starts.shape[0]
+    dev = t_starts.device
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    new_cnts = torch.empty(R, dtype=torch.int64, device=dev)
+    _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+              _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
+              ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    new_packed, total = pack_info_from_counts(new_cnts)
+    m = int(total.item())
+    o_ri = torch.empty(m, dtype=torch.int32, device=dev)
+    o_ts = torch.empty(m, dtype=torch.float32, device=dev)
+    o_te = torch.empty(m, dtype=torch.float32, device=dev)
+    if m > 0:
+        _lib.call("lse_compact_samples", ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(packed_info.data_ptr()),
+                  ctypes.c_void_p(new_packed.data_ptr()), R, _chk(ray_indices, torch.int32, "ray_indices"),
+                  _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), ctypes.c_void_p(o_ri.data_ptr()),
+                  ctypes.c_void_p(o_ts.data_ptr()), ctypes.c_void_p(o_te.data_ptr()), _stream())
+    return o_ri, o_ts, o_te, new_packed, mask
+
+
+# ----------------------------------------------------------------------------------------------------
+# positions (frustum mid-point -> contraction -> [0,1] -> selector)
+# ----------------------------------------------------------------------------------------------------
+class _PositionsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction: bool, aabb6):
+        direct = ray_idx is None
+        n = rays_o.shape[0] if direct else ray_idx.shape[0]
+        x01 = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device)
+        sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
+        aabb_arr = (ctypes.c_float * 6)(*aabb6) if aabb6 is not None else None
+        _lib.call("lse_positions_fwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
+                  _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
+                  _f32(t_ends, "t_ends", True), n, int(contraction), aabb_arr, ctypes.c_void_p(x01.data_ptr()),
+                  ctypes.c_void_p(sel.data_ptr()), _stream())
+        ctx.save_for_backward(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
+        ctx.contraction, ctx.aabb6, ctx.n = contraction, aabb6, n
+        ctx.mark_non_differentiable(sel)
+        return x01, sel
+
+    @staticmethod
+    def backward(ctx, d_x01, _d_sel):
+        rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info = ctx.saved_tensors
+        n = ctx.n
+        d_x01 = _c(d_x01)
+        d_pos = torch.empty((n, 3), dtype=torch.float32, device=d_x01.device)
+        aabb_arr = (ctypes.c_float * 6)(*ctx.aabb6) if ctx.aabb6 is not None else None
+        _lib.call("lse_positions_bwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
+                  _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
+                  _f32(t_ends, "t_ends", True), n, int(ctx.contraction), aabb_arr, _f32(d_x01, "d_x01"),
+                  ctypes.c_void_p(d_pos.data_ptr()), _stream())
+        if ray_idx is None:
+            return d_pos, None, None, None, None, None, None, None
+        if packed_info is None:
+            raise _lib.LseHipError("positions backward w.r.t. rays needs packed_info")
+        R = rays_o.shape[0]
+        d_o = torch.empty_like(rays_o) if ctx.needs_input_grad[0] else None
+        d_d = torch.empty_like(rays_d) if ctx.needs_input_grad[1] else None
+        if d_o is not None or d_d is not None:
+            _lib.call("lse_ray_grad_reduce", ctypes.c_void_p(d_pos.data_ptr()), _f32(t_starts, "t_starts"),
+                      _f32(t_ends, "t_ends"), _chk(packed_info, torch.int64, "packed_info"), R,
+                      _f32(d_o, "d_o", True), _f32(d_d, "d_d", True), _stream())
+        return d_o, d_d, None, None, None, None, None, None
+
+
+def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction=True, aabb6=None):
+    """Sample positions in the field's unit cube + in-bounds selector (R:lse_nerf/lse_field.py:266-274).
+    ``ray_idx is None``: ``rays_o`` holds positions directly (Field.density_fn)."""
+    return _PositionsFn.apply(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction, aabb6)
+
+
+# ----------------------------------------------------------------------------------------------------
+# hash grid
+# ----------------------------------------------------------------------------------------------------
+class _HashFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x01, table, meta: GridMeta):
+        n = x01.shape[0]
+        y = torch.empty((meta.n_levels, n, meta.n_features), dtype=torch.float32, device=x01.device)
+        desc = meta.desc()
+        _lib.call("lse_hash_fwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(table, "table"),
+                  ctypes.c_void_p(y.data_ptr()), n, _stream())
+        ctx.save_for_backward(x01, table)
+        ctx.meta = meta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x01, table = ctx.saved_tensors
+        meta = ctx.meta
+        n = x01.shape[0]
+        dy = _c(dy)
+        dtable = torch.zeros_like(table)
+        dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
+        desc = meta.desc()
+        _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                  ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
+        return dx, dtable, None
+
+
+def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> torch.Tensor:
+    """tcnn HashGrid forward.  Returns level-major features y[L, N, F] (the fused MLP consumes this directly);
+    ``y.permute(1, 0, 2).reshape(N, L*F)`` is the [N, L*F] tensor tcnn's torch binding returns."""
+    return _HashFn.apply(x01, table, meta)
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused MLP
+# ----------------------------------------------------------------------------------------------------
+class _MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, x, row_bias, row_bias_idx, bias_packed_info, meta: MlpMeta, n: int):
+        dev = params.device
+        out = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        need_grad = any(t is not None and t.requires_grad for t in (params, x, row_bias))
+        act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev) if need_grad else None
+        desc = meta.desc()
+        _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
+                  _f32(row_bias, "row_bias", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True),
+                  ctypes.c_void_p(out.data_ptr()), _f32(act, "act", True), n, _stream())
+        ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info)
+        ctx.meta, ctx.n = meta, n
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        params, x, act, out, row_bias, row_bias_idx, bias_packed_info = ctx.saved_tensors
+        meta, n = ctx.meta, ctx.n
+        dev = params.device
+        d_out = _c(d_out)
+        d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        d_act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev)
+        d_in = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        desc = meta.desc()
+        _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(act, "act"), _f32(out, "out"),
+                  _f32(d_out, "d_out"), ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()),
+                  _f32(d_in, "d_in", True), n, _stream())
+        d_params = None
+        if ctx.needs_input_grad[0]:
+            d_params = torch.zeros_like(params)
+            _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
+                      ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
+                      ctypes.c_void_p(d_params.data_ptr()), n, _stream())
+        d_bias = None
+        if row_bias is not None and ctx.needs_input_grad[2]:
+            if row_bias_idx is None:
+                d_bias = d_act[0]
+            elif bias_packed_info is not None:
+                d_bias = torch.zeros_like(row_bias)
+                _lib.call("lse_segment_sum_rows", ctypes.c_void_p(d_act.data_ptr()), meta.width,
+                          _chk(bias_packed_info, torch.int64, "bias_packed_info"), row_bias.shape[0],
+                          ctypes.c_void_p(d_bias.data_ptr()), _stream())
+            else:   # unsorted row indices: generic scatter-add (not on the hot path)
+                d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act[0])
+        return d_params, d_in, d_bias, None, None, None, None
+
+
+def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None):
+    """Bias-free fused MLP (tcnn layout).  Returns the padded output [n, 16].
+    ``row_bias[rows, width]`` is added to the layer-0 pre-activation of sample i from row ``row_bias_idx[i]``;
+    ``bias_packed_info[rows, 2]`` (start, count) must describe those rows' contiguous sample segments."""
+    return _MlpFn.apply(params, x, row_bias, row_bias_idx, bias_packed_info, meta, n)
+
+
+# ----------------------------------------------------------------------------------------------------
+# density activation
+# ----------------------------------------------------------------------------------------------------
+class _DensityFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, selector, scale: float):
+        n = h.shape[0]
+        sigma = torch.empty(n, dtype=torch.float32, device=h.device)
+        _lib.call("lse_density_fwd", _f32(h, "h"), _chk(selector, torch.uint8, "selector", True), float(scale),
+                  ctypes.c_void_p(sigma.data_ptr()), n, _stream())
+        ctx.save_for_backward(h, selector)
+        ctx.scale = scale
+        return sigma
+
+    @staticmethod
+    def backward(ctx, d_sigma):
+        h, selector = ctx.saved_tensors
+        n = h.shape[0]
+        d_h = torch.zeros_like(h)
+        _lib.call("lse_density_bwd", _f32(h, "h"), _chk(selector, torch.uint8, "selector", True), float(ctx.scale),
+                  _f32(_c(d_sigma), "d_sigma"), ctypes.c_void_p(d_h.data_ptr()), n, _stream())
+        return d_h, None, None
+
+
+def density_from_mlp_out(h: torch.Tensor, selector: Optional[torch.Tensor], scale: float = 1.0) -> torch.Tensor:
+    """sigma[N] = scale * trunc_exp(h[:,0]) * selector  (R:lse_nerf/lse_field.py:286-287); h is the [N,16] base output."""
+    return _DensityFn.apply(h, selector, scale)
+
+
+# ----------------------------------------------------------------------------------------------------
+# per-ray head features and small dense layers
+# ----------------------------------------------------------------------------------------------------
+class _RayFeaturesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_d, emb_table, emb_idx):
+        R = rays_d.shape[0]
+        emb_dim = 0 if emb_table is None else emb_table.shape[1]
+        feat = torch.empty((R, 64), dtype=torch.float32, device=rays_d.device)
+        _lib.call("lse_ray_features_fwd", _f32(rays_d, "rays_d"), _f32(emb_table, "emb_table", True),
+                  _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim, ctypes.c_void_p(feat.data_ptr()), _stream())
+        ctx.save_for_backward(rays_d, emb_table, emb_idx)
+        return feat
+
+    @staticmethod
+    def backward(ctx, d_feat):
+        rays_d, emb_table, emb_idx = ctx.saved_tensors
+        R = rays_d.shape[0]
+        emb_dim = 0 if emb_table is None else emb_table.shape[1]
+        d_feat = _c(d_feat)
+        d_dirs = torch.empty_like(rays_d) if ctx.needs_input_grad[0] else None
+        d_emb = torch.zeros_like(emb_table) if (emb_table is not None and ctx.needs_input_grad[1]) else None
+        _lib.call("lse_ray_features_bwd", _f32(rays_d, "rays_d"), _f32(d_feat, "d_feat"),
+                  _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim, _f32(d_dirs, "d_dirs", True),
+                  _f32(d_emb, "d_emb", True), _stream())
+        return d_dirs, d_emb, None
+
+
+def ray_features(rays_d, emb_table=None, emb_idx=None):
+    """[R,64] = [SH16 | 15 zeros | emb32 | 1] per ray (tcnn SH-4 of the shifted direction)."""
+    return _RayFeaturesFn.apply(rays_d, emb_table, emb_idx)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y[R,M] = x[R,K] @ w[M,K]^T on the HIP helpers (per-ray matrices only)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        R, K = x.shape
+        M = w.shape[0]
+        y = torch.empty((R, M), dtype=torch.float32, device=x.device)
+        _lib.call("lse_linear_fwd", _f32(w, "w"), _f32(x, "x"), R, M, K, ctypes.c_void_p(y.data_ptr()), _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        R, K = x.shape
+        M = w.shape[0]
+        dy = _c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("lse_linear_bwd_input", _f32(w, "w"), _f32(dy, "dy"), R, M, K, ctypes.c_void_p(dx.data_ptr()),
+                      _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            _lib.call("lse_gemm_tn_acc", _f32(dy, "dy"), M, _f32(x, "x"), K, _lib.LSE_IN_ROWMAJOR, R,
+                      ctypes.c_void_p(dw.data_ptr()), K, _stream())
+        return dx, dw
+
+
+def linear(x, w):
+    return _LinearFn.apply(x, w)
+
+
+# ----------------------------------------------------------------------------------------------------
+# volume rendering
+# ----------------------------------------------------------------------------------------------------
+class _VolRendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t_starts, t_ends, sigmas, rgb, packed_info):
+        R = packed_info.shape[0]
+        n = t_starts.shape[0]
+        dev = t_starts.device
+        weights = torch.empty(n, dtype=torch.float32, device=dev)
+        out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev) if rgb is not None else None
+        out_acc = torch.empty(R, dtype=torch.float32, device=dev)
+        out_dep = torch.empty(R, dtype=torch.float32, device=dev)
+        stride = rgb.stride(0) if rgb is not None else 0
+        _lib.call("lse_volrend_fwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _rgb_ptr(rgb), stride, _chk(packed_info, torch.int64, "packed_info"), R,
+                  ctypes.c_void_p(weights.data_ptr()), _f32(out_rgb, "out_rgb", True),
+                  ctypes.c_void_p(out_acc.data_ptr()), ctypes.c_void_p(out_dep.data_ptr()), _stream())
+        ctx.save_for_backward(t_starts, t_ends, sigmas, rgb, packed_info, weights)
+        ctx.mark_non_differentiable(weights)
+        if out_rgb is None:
+            out_rgb = torch.zeros((R, 3), dtype=torch.float32, device=dev)
+        return out_rgb, out_acc, out_dep, weights
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, g_dep, _g_w):
+        t_starts, t_ends, sigmas, rgb, packed_info, weights = ctx.saved_tensors
+        R = packed_info.shape[0]
+        d_sigma = torch.zeros_like(sigmas)
+        d_rgb = torch.zeros_like(rgb) if (rgb is not None and ctx.needs_input_grad[3]) else None
+        stride = rgb.stride(0) if rgb is not None else 0
+        _lib.call("lse_volrend_bwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _rgb_ptr(rgb), stride, _chk(packed_info, torch.int64, "packed_info"), R, _f32(weights, "weights"),
+                  _f32(_c(g_rgb), "g_rgb", True) if g_rgb is not None else None,
+                  _f32(_c(g_acc), "g_acc", True) if g_acc is not None else None,
+                  _f32(_c(g_dep), "g_dep", True) if g_dep is not None else None,
+                  ctypes.c_void_p(d_sigma.data_ptr()), _rgb_ptr(d_rgb), _stream())
+        return None, None, d_sigma, d_rgb, None
+
+
+def _rgb_ptr(rgb):
+    if rgb is None:
+        return None
+    if not rgb.is_cuda or rgb.dtype != torch.float32 or rgb.dim() != 2 or rgb.stride(1) != 1 or rgb.stride(0) < 3:
+        raise ValueError("rgb must be a float32 GPU matrix [N, >=3] with unit column stride")
+    return ctypes.c_void_p(rgb.data_ptr())
+
+
+def volume_render(t_starts, t_ends, sigmas, rgb, packed_info):
+    """render_weight_from_density + accumulate_along_rays (R:lse_nerf/lsenerf.py:301-318).
+    ``rgb`` may be the padded [N,16] head output (only columns 0..2 are read).
+    Returns (rgb[R,3], accumulation[R], depth_numerator[R] = sum w*(ts+te)/2, weights[N])."""
+    return _VolRendFn.apply(t_starts, t_ends, sigmas, rgb, packed_info)
+
+
+# ----------------------------------------------------------------------------------------------------
+# optimiser / occupancy grid
+# ----------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step: int, grad_scale: float = 1.0):
+    _lib.call("lse_adam_step", _f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"),
+              _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), float(lr), float(beta1), float(beta2), float(eps),
+              int(step), float(grad_scale), _stream())
+
+
+@torch.no_grad()
+def occ_update_cells(occs, cell_ids, occ_new, ema_decay: float):
+    n = cell_ids.shape[0]
+    ws = torch.empty(n, dtype=torch.float32, device=occs.device)
+    _lib.call("lse_occ_update_cells", _f32(occs, "occs"), _chk(cell_ids, torch.int64, "cell_ids"),
+              _f32(occ_new, "occ_new"), n, float(ema_decay), ctypes.c_void_p(ws.data_ptr()), _stream())
+
+
+@torch.no_grad()
+def occ_binarize(occs, threshold: torch.Tensor, binaries_u8):
+    _lib.call("lse_occ_binarize", _f32(occs, "occs"), occs.numel(), _f32(threshold, "threshold"),
+              _chk(binaries_u8, torch.uint8, "binaries"), _stream())

@@ -1,0 +1,74 @@
+"""Flat-buffer optimiser state for the hot path.
+
+All trainable tensors of a model are re-pointed into ONE contiguous fp32 buffer (``FlatParams``): their ``.data``
+and ``.grad`` become views, so that
+  * the gradient of the whole model is one tensor -> one RCCL all-reduce per step over xGMI (lsenerf_amd.dist),
+  * Adam is one streaming HIP kernel over (p, g, m, v)  (lse_adam_step),
+  * zeroing gradients is one memset.
+Semantics are torch.optim.Adam's with the reference's hyper-parameters (lr 1e-2, eps 1e-15, exponential decay to
+1e-4 over 200k steps: R:lse_nerf/lse_config.py:29-33).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, params: Iterable[nn.Parameter], align: int = 64):
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        assert len(self.params) > 0
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.device == dev
+            offs.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.offsets, self.numel = offs, total
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):   # keep .grad a view (autograd then accumulates in place)
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps) on a FlatParams, one HIP kernel per step."""
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15,
+                 lr_final: Optional[float] = None, max_steps: Optional[int] = None):
+        self.flat = flat
+        self.lr_init, self.betas, self.eps = lr, betas, eps
+        self.lr_final, self.max_steps = lr_final, max_steps
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_count = 0
+
+    def current_lr(self) -> float:
+        """nerfstudio ExponentialDecayScheduler (no warm-up): lr_init * (lr_final/lr_init)^(t/max_steps)."""
+        if self.lr_final is None or not self.max_steps:
+            return self.lr_init
+        t = min(max(self.step_count / self.max_steps, 0.0), 1.0)
+        import math
+        return math.exp(math.log(self.lr_init) * (1 - t) + math.log(self.lr_final) * t)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale: float = 1.0):
+        lr = self.current_lr()
+        self.step_count += 1
+        ops.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
+                      self.eps, self.step_count, grad_scale)

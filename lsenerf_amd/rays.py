@@ -1,0 +1,57 @@
+"""Minimal duck-typed stand-ins for nerfstudio's ``RayBundle`` / ``Frustums`` / ``RaySamples``
+(nerfstudio 0.3.2 ``cameras/rays.py``; not importable here).  Only the attributes the hot path touches
+(R:lse_nerf/lsenerf.py:278-326, R:lse_nerf/lse_field.py:264-360) are modelled, with the same names and shapes."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+
+@dataclass
+class RayBundle:
+    origins: Tensor                       # [R,3]
+    directions: Tensor                    # [R,3] unit
+    pixel_area: Optional[Tensor] = None   # [R,1]
+    camera_indices: Optional[Tensor] = None  # [R,1] int
+    nears: Optional[Tensor] = None        # [R,1]
+    fars: Optional[Tensor] = None         # [R,1]
+    times: Optional[Tensor] = None
+    metadata: Dict[str, Tensor] = field(default_factory=dict)
+
+    def __len__(self) -> int:
+        return self.origins.shape[0]
+
+
+@dataclass
+class Frustums:
+    origins: Tensor      # [N,3]
+    directions: Tensor   # [N,3]
+    starts: Tensor       # [N,1]
+    ends: Tensor         # [N,1]
+    pixel_area: Optional[Tensor] = None
+
+    @property
+    def shape(self):
+        return self.origins.shape[:-1]
+
+    def get_positions(self) -> Tensor:
+        """nerfstudio: origins + directions * (starts + ends) / 2."""
+        return self.origins + self.directions * (self.starts + self.ends) / 2
+
+
+@dataclass
+class RaySamples:
+    frustums: Frustums
+    camera_indices: Optional[Tensor] = None   # [N,1]
+    times: Optional[Tensor] = None
+    metadata: Dict[str, Tensor] = field(default_factory=dict)
+    # packed-sample bookkeeping the HIP path adds (absent upstream; optional for callers)
+    ray_indices: Optional[Tensor] = None      # [N] int32, sorted
+    packed_info: Optional[Tensor] = None      # [R,2] int64
+    ray_bundle: Optional[RayBundle] = None
+
+    def __len__(self) -> int:
+        return self.frustums.origins.shape[0]

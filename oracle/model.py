@@ -50,7 +50,10 @@ class ModelOracle:
         self.field.training = self.training
         pos = frustum_positions(origins[ray_indices], directions[ray_indices], t_starts[:, None], t_ends[:, None])
         density, geo = self.field.get_density(pos)
-        aid = None if appearance_id is None else appearance_id[ray_indices]
+        if appearance_id is None:   # GlobalEmbedding: index camera_indices * 0 (R:lse_nerf/lse_embeddings.py:80-82)
+            aid = torch.zeros(ray_indices.shape[0], dtype=torch.int64)
+        else:
+            aid = appearance_id[ray_indices]
         rgb = self.field.get_outputs(directions[ray_indices], geo, aid)
         packed_info = vr.pack_info(ray_indices, num_rays)
         weights = vr.render_weight_from_density(t_starts, t_ends, density[..., 0], packed_info)[0][..., None]

@@ -1,0 +1,156 @@
+"""Shared helpers for the parity tests: seeded inputs, HIP-model/oracle pairs with identical parameters, error metrics.
+
+The oracle (``oracle/``) is the checker only; everything named ``hip_*`` runs through the C-ABI on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+# stated tolerances (normalised max error: max|a-b| / max(floor, max|b|))
+TOL_FWD = 2e-5     # forward activations / renders, fp32 with different summation orders
+TOL_GRAD = 3e-4    # gradients: long sums (N up to 1e5 terms) in different orders, float atomics
+
+
+def nmax_err(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-6) -> float:
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / max(floor, float(b.abs().max())))
+
+
+def random_rays(n: int, seed: int = 0, inside: bool = False, device="cpu"):
+    """origins on the radius-1.5 sphere aimed at random targets in [-0.5,0.5]^3
+    (``inside``: origins uniformly in [-0.5,0.5]^3, random unit directions)."""
+    g = torch.Generator().manual_seed(seed)
+    if inside:
+        o = torch.rand(n, 3, generator=g) - 0.5
+        d = torch.randn(n, 3, generator=g)
+    else:
+        o = torch.randn(n, 3, generator=g)
+        o = 1.5 * o / o.norm(dim=-1, keepdim=True)
+        tgt = torch.rand(n, 3, generator=g) - 0.5
+        d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.to(device).contiguous(), d.to(device).contiguous()
+
+
+def random_binaries(levels: int, res: int, frac: float, seed: int = 0) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand((levels, res, res, res), generator=g) < frac
+
+
+def make_model_pair(grid_levels=4, grid_resolution=128, seed=96, occupied_frac=0.3, num_levels=16, hidden=64,
+                    emb_type="global_emb", num_train_data=8, contraction=True, alpha_thre=0.01, cone_angle=0.004,
+                    log2_hashmap_size=19, param_scale: float = 1.0):
+    """(HIP model on cuda:0, ModelOracle on CPU) sharing parameters, occupancy grid and hyper-parameters."""
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, LSEEmbeddingConfig
+    from oracle.field import FieldOracle
+    from oracle.model import ModelOracle
+
+    torch.manual_seed(seed)
+    cfg = LSENeRFModelConfig(grid_levels=grid_levels, grid_resolution=grid_resolution, num_levels=num_levels,
+                             hidden_dim=hidden, hidden_dim_color=hidden, alpha_thre=alpha_thre, cone_angle=cone_angle,
+                             log2_hashmap_size=log2_hashmap_size, disable_scene_contraction=not contraction,
+                             embed_config=LSEEmbeddingConfig(embedding_type=emb_type))
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    hip = LSENeRFModel(cfg, aabb, num_train_data)
+    if param_scale != 1.0:   # larger table values make the hash contribution visible above fp32 noise
+        with torch.no_grad():
+            hip.field.mlp_base_grid.params.mul_(param_scale)
+    hip = hip.cuda()
+    n_emb = hip.field.embedding_appearance.embedding.weight.shape[0]
+    f = FieldOracle("tcnn", num_levels=num_levels, hidden_dim=hidden, hidden_dim_color=hidden,
+                    log2_hashmap_size=log2_hashmap_size, num_embeddings=n_emb, contraction=contraction, aabb=aabb,
+                    seed=seed)
+    sync_params_to_oracle(hip, f)
+    orc = ModelOracle(f, grid_resolution=grid_resolution, grid_levels=grid_levels, alpha_thre=alpha_thre,
+                      cone_angle=cone_angle)
+    b = random_binaries(grid_levels, grid_resolution, occupied_frac, seed)
+    occs = b.float().flatten() * 0.5
+    hip.occupancy_grid.binaries.copy_(b.cuda())
+    hip.occupancy_grid.occs.copy_(occs.cuda())
+    hip.occupancy_grid._occ_mean_host = None
+    orc.grid.binaries = b.clone()
+    orc.grid.occs = occs.clone()
+    assert abs(orc.render_step_size - cfg.render_step_size) < 1e-12
+    return hip, orc
+
+
+def sync_params_to_oracle(hip, field_oracle):
+    fld = hip.field
+    src = {"grid": fld.mlp_base_grid.params, "base": fld.mlp_base_mlp.params, "head": fld.mlp_head.params,
+           "embedding": fld.embedding_appearance.embedding.weight}
+    for k, v in src.items():
+        assert field_oracle.params[k].shape == v.shape, (k, field_oracle.params[k].shape, v.shape)
+        field_oracle.params[k] = v.detach().cpu().clone().requires_grad_(True)
+    # the oracle's own level table must agree with the product's (independent restatements of tcnn's constructor)
+    m, mo = fld.mlp_base_grid.meta, field_oracle.meta
+    assert list(m.offsets) == list(mo.offsets) and list(m.resolutions) == list(mo.resolutions)
+    assert np.allclose(np.float32(m.scales), np.float32(mo.scales), rtol=0, atol=0)
+
+
+def compare_model_outputs(hip, orc, o, d, appearance_id: Optional[torch.Tensor], check_grads=True,
+                          jitter: Optional[torch.Tensor] = None) -> Dict[str, float]:
+    """Runs hip.exec_get_outputs on the GPU, re-renders THE SAME packed samples through the oracle, compares renders
+    and (optionally) every parameter gradient + ray gradients.  Sampler parity is tested separately (bit-exact)."""
+    from lsenerf_amd import RayBundle
+    hip.train()
+    orc.training = True
+    R = o.shape[0]
+    og = o.clone().cuda().requires_grad_(True)
+    dg = d.clone().cuda().requires_grad_(True)
+    meta = {}
+    if appearance_id is not None:
+        meta["appearance_id"] = appearance_id.cuda()
+    rb = RayBundle(origins=og, directions=dg, camera_indices=torch.zeros(R, 1, dtype=torch.long, device="cuda"),
+                   metadata=meta)
+    if jitter is None:
+        jitter = torch.rand(R, generator=torch.Generator().manual_seed(7))
+    # sampler on the GPU; the same samples go to the oracle
+    rs, li = hip.sampler(ray_bundle=rb, near_plane=hip.config.near_plane, far_plane=hip.config.far_plane,
+                         render_step_size=hip.config.render_step_size, alpha_thre=hip.config.alpha_thre,
+                         cone_angle=hip.config.cone_angle, jitter=jitter.cuda())
+    ts, te = rs.frustums.starts[..., 0].contiguous(), rs.frustums.ends[..., 0].contiguous()
+    out = hip.render_packed(rb, rs.ray_indices, ts, te, rs.packed_info)
+
+    oc = o.clone().requires_grad_(True)
+    dc = d.clone().requires_grad_(True)
+    for p in orc.field.parameters():
+        p.grad = None
+    ref = orc.render_samples(oc, dc, li.cpu(), ts.cpu(), te.cpu(), appearance_id)
+    res = {
+        "n_samples": float(ts.shape[0]),
+        "rgb": nmax_err(out["rgb"], ref["rgb"], 1e-3),
+        "acc": nmax_err(out["accumulation"], ref["accumulation"], 1e-3),
+        "depth": nmax_err(out["depth"], ref["depth"], 1e-3),
+    }
+    assert torch.equal(out["num_samples_per_ray"].cpu(), ref["num_samples_per_ray"])
+    assert res["rgb"] < TOL_FWD * 5 and res["acc"] < TOL_FWD * 5 and res["depth"] < TOL_FWD * 5, res
+    if check_grads:
+        g = torch.Generator().manual_seed(3)
+        wr = torch.rand(R, 3, generator=g)
+        wa = torch.rand(R, 1, generator=g)
+        wd = torch.rand(R, 1, generator=g)
+        for p in hip.parameters():
+            p.grad = None
+        loss = (out["rgb"] * wr.cuda()).sum() + (out["accumulation"] * wa.cuda()).sum() + (out["depth"] * wd.cuda()).sum()
+        loss.backward()
+        lref = (ref["rgb"] * wr).sum() + (ref["accumulation"] * wa).sum() + (ref["depth"] * wd).sum()
+        lref.backward()
+        fld = hip.field
+        pairs = {"grid": fld.mlp_base_grid.params, "base": fld.mlp_base_mlp.params, "head": fld.mlp_head.params,
+                 "embedding": fld.embedding_appearance.embedding.weight}
+        for k, p in pairs.items():
+            gref = orc.field.params[k].grad
+            assert p.grad is not None and gref is not None, k
+            res["d_" + k] = nmax_err(p.grad, gref, 1e-12)
+            assert res["d_" + k] < TOL_GRAD, (k, res)
+        res["d_origins"] = nmax_err(og.grad, oc.grad, 1e-12)
+        res["d_directions"] = nmax_err(dg.grad, dc.grad, 1e-12)
+        assert res["d_origins"] < TOL_GRAD and res["d_directions"] < TOL_GRAD, res
+    return res
