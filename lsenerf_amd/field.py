@@ -74,7 +74,7 @@ class MLP(nn.Module):
                  out_activation=None, implementation: str = "hip", in_layout: int = _lib.LSE_IN_ROWMAJOR) -> None:
         super().__init__()
         self.in_dim, self.out_dim, self.layer_width, self.num_layers = in_dim, out_dim, layer_width, num_layers
-        self.in_pad = _pad16(in_dim) if in_layout == _lib.LSE_IN_ROWMAJOR else in_dim
+        self.in_pad = _pad16(in_dim)     # tcnn pads network inputs to a multiple of 16 (with ones)
         self.n_hidden_layers = num_layers - 1
         assert out_dim <= 16, "the fused kernel pads outputs to 16"
         self.out_act = _lib.LSE_ACT_SIGMOID if isinstance(out_activation, nn.Sigmoid) or out_activation == "Sigmoid" \
@@ -95,6 +95,14 @@ class MLP(nn.Module):
         return ops.MlpMeta(self.in_pad if n_in is None else n_in, self.layer_width, self.n_hidden_layers, self.out_act,
                            self.in_layout)
 
+    def split_padding(self):
+        """For inputs narrower than the tcnn-padded width (the 8 features of an L=4 grid): kernel parameters over the
+        real columns, plus the ones-padding columns folded into one bias row [1, width]."""
+        w0 = self.first_layer()
+        kparams = torch.cat([w0[:, : self.in_dim].reshape(-1), self.rest()])
+        bias = w0[:, self.in_dim:].sum(dim=1)[None, :].contiguous()
+        return kparams, bias
+
     def first_layer(self) -> Tensor:
         return self.params[: self.layer_width * self.in_pad].view(self.layer_width, self.in_pad)
 
@@ -102,12 +110,23 @@ class MLP(nn.Module):
         return self.params[self.layer_width * self.in_pad:]
 
     def forward(self, in_tensor: Tensor) -> Tensor:
-        """Generic path (any caller): row-major input, padded with ones like tcnn's Identity encoding."""
+        """Generic path (any caller): ``in_tensor[..., in_dim]`` row-major like nerfstudio's MLP; narrower inputs are
+        padded with ones like tcnn's Identity encoding.  (The field's fast path feeds level-major features directly.)"""
         x = in_tensor.reshape(-1, in_tensor.shape[-1])
         n = x.shape[0]
-        if self.in_layout == _lib.LSE_IN_ROWMAJOR and x.shape[-1] < self.in_pad:
-            x = torch.cat([x, torch.ones(n, self.in_pad - x.shape[-1], device=x.device, dtype=x.dtype)], dim=-1)
-        out = ops.fused_mlp(self.params, x.contiguous(), self.meta(), n)
+        if self.in_layout == _lib.LSE_IN_LEVELMAJOR:
+            xl = x.reshape(n, self.in_dim // 2, 2).permute(1, 0, 2).contiguous()
+            if self.in_pad == self.in_dim:
+                out = ops.fused_mlp(self.params, xl, self.meta(), n)
+            else:
+                kparams, bias = self.split_padding()
+                idx = torch.zeros(n, dtype=torch.int32, device=x.device)
+                seg = torch.tensor([[0, n]], dtype=torch.int64, device=x.device)
+                out = ops.fused_mlp(kparams, xl, self.meta(self.in_dim), n, bias, idx, seg)
+        else:
+            if x.shape[-1] < self.in_pad:
+                x = torch.cat([x, torch.ones(n, self.in_pad - x.shape[-1], device=x.device, dtype=x.dtype)], dim=-1)
+            out = ops.fused_mlp(self.params, x.contiguous(), self.meta(), n)
         return out[:, : self.out_dim].view(*in_tensor.shape[:-1], self.out_dim)
 
 
@@ -254,7 +273,14 @@ class LSEField(nn.Module):
         x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
         n = x01.shape[0]
         y = self.mlp_base_grid.forward_levelmajor(x01)
-        h = ops.fused_mlp(self.mlp_base_mlp.params, y, self.mlp_base_mlp.meta(), n)
+        mlp = self.mlp_base_mlp
+        if mlp.in_pad == mlp.in_dim:
+            h = ops.fused_mlp(mlp.params, y, mlp.meta(), n)
+        else:   # small grids (L*F < 16): tcnn's ones-padding columns act as a bias shared by every sample
+            kparams, bias = mlp.split_padding()
+            idx = torch.zeros(n, dtype=torch.int32, device=x01.device)
+            seg = torch.tensor([[0, n]], dtype=torch.int64, device=x01.device)
+            h = ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg)
         sigma = ops.density_from_mlp_out(h, sel, self.average_init_density)
         return sigma, h, sel
 

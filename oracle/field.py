@@ -246,7 +246,7 @@ class FieldOracle:
 
     def get_density(self, positions: torch.Tensor):
         p, selector = self.normalize(positions)
-        h = self.mlp_base(p.view(-1, 3))
+        h = self.mlp_base(self.encode(p.view(-1, 3)))      # mlp_base = Sequential(grid, mlp), R:lse_nerf/lse_field.py:208
         dba, geo = torch.split(h, [1, self.geo_feat_dim], dim=-1)
         density = self.average_init_density * trunc_exp(dba)
         density = density * selector[..., None]

@@ -105,7 +105,8 @@ def test_positions_fwd_bwd(contraction):
     og, dg = o.clone().cuda().requires_grad_(True), d.clone().cuda().requires_grad_(True)
     x01, sel = ops.positions(og, dg, ri.int().cuda(), ts.cuda(), te.cuda(), packed.cuda(), contraction,
                              None if contraction else aabb.flatten().tolist())
-    assert sel_ref.float().mean() > 0.1 and sel_ref.float().mean() < 0.999
+    if not contraction:   # (the contraction maps everything into the open unit cube)
+        assert sel_ref.float().mean() > 0.1 and sel_ref.float().mean() < 0.999
     edge = (p_ref.detach() - 0.5).abs().max(-1).values > 0.49999   # in/out decisions within fp noise of the faces
     assert bool(((sel.cpu().bool() == sel_ref) | edge).all())
     keep = (sel.cpu().bool() == sel_ref)
@@ -173,6 +174,9 @@ def _mlp_case(in_dim, width, num_layers, out_dim, act, level_major, N, use_bias,
     ops = _ops()
     g = torch.Generator().manual_seed(seed)
     om = TcnnMLP(in_dim, num_layers, width, out_dim, act)
+    om.in_pad = in_dim            # kernel-level test: the kernel's n_in is already the padded width (or the 8-wide
+    om.shapes[0] = (width, in_dim)  # level-major case whose tcnn ones-padding the host folds into a bias)
+    om.n_params = sum(a * b for a, b in om.shapes)
     params = om.init_params(g)
     x = torch.randn(N, in_dim, generator=g)
     R = 37

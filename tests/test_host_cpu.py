@@ -1,0 +1,152 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/lse_hip.h declares, descriptor
+structs match the header, host logic (level tables, flat parameter buffers, config coercions, module wiring, error
+behaviour) works without a GPU.  No compute calls are made here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "lse_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lse_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lsenerf_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
+    # and the binding covers exactly the header (no stale or missing signatures)
+    assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error"} == set(names)
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 1
+
+
+def test_argument_counts_match_header():
+    from lsenerf_amd import _lib
+    src = open(os.path.join(ROOT, "include", "lse_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name, argtypes in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        n_args = len([a for a in m.group(1).split(",") if a.strip()])
+        assert n_args == len(argtypes), (name, n_args, len(argtypes))
+
+
+def test_descriptor_struct_layouts():
+    from lsenerf_amd import _lib
+    assert ctypes.sizeof(_lib.GridDesc) == 4 + 4 + 33 * 4 + 32 * 4 + 32 * 4
+    assert ctypes.sizeof(_lib.MlpDesc) == 20
+
+
+def test_invalid_arguments_fail_loudly_without_gpu():
+    """Argument validation happens before any launch, so these error paths are exercised on CPU."""
+    from lsenerf_amd import _lib
+    lib = _lib.load()
+    d = _lib.MlpDesc(24, 64, 1, 0, 0)
+    rc = lib.lse_mlp_fwd(ctypes.byref(d), None, None, None, None, None, None, 8, None)
+    assert rc == -1 and b"n_in" in lib.lse_last_error()
+    g = _lib.GridDesc()
+    g.n_levels, g.n_features = 16, 4
+    rc = lib.lse_hash_fwd(ctypes.byref(g), None, None, None, 8, None)
+    assert rc == -1 and b"n_features" in lib.lse_last_error()
+    with pytest.raises(_lib.LseHipError):
+        _lib.call("lse_traverse_grids", None, None, 4, None, None, 1, 8, 8, 8, None, None, 0.1, 0.0, 0, None, None, None,
+                  None, None, None)
+    # zero-sized work is a no-op, not an error
+    assert lib.lse_volrend_fwd(None, None, None, None, 0, None, 0, None, None, None, None, None) == 0
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    from lsenerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblse_hip.so")
+    with pytest.raises(_lib.LseHipError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    from lsenerf_amd import _lib, ops
+    with pytest.raises(_lib.LseHipError, match="no CPU fallback"):
+        ops.hash_encode(torch.rand(4, 3), torch.rand(16), ops.make_grid_meta(n_levels=4, log2_hashmap_size=4))
+
+
+def test_grid_meta_matches_oracle_restatement():
+    from lsenerf_amd import ops
+    from oracle import hashgrid as hg
+    for kw in (dict(), dict(n_levels=4, log2_hashmap_size=12), dict(n_levels=16, log2_hashmap_size=14, max_res=1024)):
+        a, b = ops.make_grid_meta(**kw), hg.tcnn_grid_meta(**kw)
+        assert list(a.offsets) == b.offsets and list(a.resolutions) == b.resolutions and list(a.scales) == b.scales
+    m = ops.make_grid_meta()
+    assert m.n_params == 12196240
+    d = m.desc()
+    assert d.n_levels == 16 and d.offsets[16] == 6098120 and d.resolutions[0] == 16
+
+
+def test_model_wiring_and_param_groups():
+    import lsenerf_amd as la
+    cfg = la.LSENeRFModelConfig(evs_mapping_method="None", map_mode="None", ev_one_dim="True", rgb_loss_type="None")
+    assert cfg.evs_mapping_method is None and cfg.map_mode == "evs_rgb" and cfg.ev_one_dim == "learned"
+    assert cfg.rgb_loss_type == "linspace"
+    m = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map",
+                                              evs_mapping_method="powpow"), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 12)
+    assert abs(m.config.render_step_size - 0.0034641016) < 1e-9                      # R:lse_nerf/lsenerf.py:180-182
+    assert isinstance(m.renderer_rgb, la.LinearRenderer)                              # :209-213
+    assert m.occupancy_grid.binaries.shape == (4, 128, 128, 128) and m.occupancy_grid.aabbs[3].tolist() == [-8.0] * 3 + [8.0] * 3
+    names = {n for n, _ in m.field.named_parameters()}
+    assert names == {"mlp_base_grid.params", "mlp_base_mlp.params", "mlp_head.params",
+                     "embedding_appearance.embedding.weight"}
+    assert m.field.mlp_base_mlp.params.numel() == 3072 and m.field.mlp_head.params.numel() == 9216
+    groups = m.get_param_groups()
+    assert set(groups) == {"fields"}
+    n = sum(p.numel() for p in groups["fields"])
+    assert n == 12196240 + 3072 + 9216 + 32 + 3 + 1        # grid + MLPs + global embedding + ThreeToOne + Powpow
+    assert not any(k.startswith("hash_table") for k in names)  # the reference's dead 67 MB table is not allocated
+
+
+def test_flat_params_and_adam_schedule_cpu():
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    a, b = torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(70))
+    a0 = a.detach().clone()
+    flat = FlatParams([a, b])
+    assert torch.equal(a.detach(), a0) and a.data_ptr() == flat.data.data_ptr()
+    (a.sum() * 2 + (b * b).sum()).backward()
+    assert torch.allclose(flat.grad[:15], torch.full((15,), 2.0)) and flat.grad.data_ptr() == a.grad.data_ptr()
+    assert torch.allclose(flat.grad[flat.offsets[1]:flat.offsets[1] + 70], 2 * b.detach())
+    flat.zero_grad()
+    assert float(flat.grad.abs().sum()) == 0 and a.grad.data_ptr() == flat.grad.data_ptr()
+    opt = FlatAdam.__new__(FlatAdam)
+    opt.lr_init, opt.lr_final, opt.max_steps, opt.step_count = 1e-2, 1e-4, 200000, 0
+    assert abs(opt.current_lr() - 1e-2) < 1e-12
+    opt.step_count = 200000
+    assert abs(opt.current_lr() - 1e-4) < 1e-12
+    opt.step_count = 100000
+    assert abs(opt.current_lr() - 1e-3) < 1e-9
+
+
+def test_embedding_modes_and_errors():
+    import lsenerf_amd as la
+    from lsenerf_amd.field import EvsFrameEmbedding, GlobalEmbedding
+    f = la.LSEField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 10, embd_config=la.LSEEmbeddingConfig("evs_emb"))
+    assert isinstance(f.embedding_appearance, EvsFrameEmbedding) and f.embedding_appearance.embedding.weight.shape == (10, 32)
+    g = la.LSEField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 10)
+    assert isinstance(g.embedding_appearance, GlobalEmbedding) and g.embedding_appearance.embedding.weight.shape == (1, 32)
+    rs = la.RaySamples(la.Frustums(torch.zeros(2, 3), torch.zeros(2, 3), torch.zeros(2, 1), torch.zeros(2, 1)))
+    with pytest.raises(AssertionError):
+        g.get_outputs(rs, None)                                    # R:lse_nerf/lse_field.py:293
+    with pytest.raises(AttributeError, match="Camera indices are not provided."):
+        g.get_outputs(rs, torch.zeros(2, 15))                      # R:lse_nerf/lse_field.py:295-296
+    f.eval()
+    tab, idx = f._eval_emb(4, "cpu")
+    assert tab is None and idx is None                             # eval_mode "zero" (R:lse_nerf/lse_embeddings.py:51-55)
+    est = la.LSEOccGridEstimator([-1, -1, -1, 1, 1, 1], 8, 2)
+    est.eval()
+    with pytest.raises(RuntimeError):
+        est.update_every_n_steps(0, lambda x: x)
