@@ -28,6 +28,9 @@ RAYS_PER_GPU = 4096
 SAMPLES_PER_RAY = 1024
 BYTES_PER_SAMPLE_STEP = 2136           # 1024 gather + 1024 scatter + 88 packed streams
 HASH_BYTES_PER_SAMPLE = 1024           # L*8*F*4: algorithmic bytes of one hash gather / scatter pass
+# fused-MLP flops per sample, fwd + bwd(data) + wgrad, as executed (base 32->64->16, head 16(+per-ray bias)->64->64->16):
+# fwd 2*(32*64+64*16) + 2*(16*64+64*64+64*16) = 18432; bwd data = same contraction sizes; wgrad = same  -> 3x
+MLP_FLOP_PER_SAMPLE = 3 * 18432
 HBM_PEAK = 8.0e12                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -77,11 +80,11 @@ def cpu_baseline(seconds_budget=25.0):
     restated in oracle/) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle.field import FieldOracle
     from oracle.model import ModelOracle, cpu_train_step_packed
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)        # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(cores)
     f = FieldOracle("torch", num_embeddings=64, seed=96)
     m = ModelOracle(f, cone_angle=0.0, alpha_thre=0.0)
-    R = 32
+    R = 16
     g = torch.Generator().manual_seed(0)
     o = torch.rand(R, 3, generator=g) - 0.5
     d = torch.randn(R, 3, generator=g)
@@ -93,12 +96,12 @@ def cpu_baseline(seconds_budget=25.0):
     target = torch.rand(R, 3, generator=g)
     aid = torch.randint(0, 64, (R,), generator=g)
     state = {}
-    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=16)      # warm-up
+    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=8)      # warm-up
     times = []
     t_all = time.time()
     while len(times) < 5 and (time.time() - t_all) < seconds_budget:
         t0 = time.time()
-        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=16)
+        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=8)
         times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": R / med, "unit": "rays/s", "cores": cores, "kind": "port",
@@ -180,6 +183,9 @@ def main():
             "step_roofline": {"algorithmic_bytes_per_step": b_step,
                               "achieved_GBps": b_step / (ms_per_step * 1e-3) / 1e9 * 1.0,
                               "frac_of_hbm_peak": b_step / (ms_per_step * 1e-3) / HBM_PEAK},
+            "mfma": {"kernels": "lse_mlp_fwd+lse_mlp_bwd+lse_mlp_wgrad", "flop_per_sample": MLP_FLOP_PER_SAMPLE,
+                     "achieved_TFLOPs": MLP_FLOP_PER_SAMPLE * n_samples / (1e-3 * (kern_ms.get("lse_mlp_fwd", 0) + kern_ms.get(
+                         "lse_mlp_bwd", 0) + kern_ms.get("lse_mlp_wgrad", 0) + 1e-9)) / 1e12, "peak_TFLOPs": 157.3},
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
             "loss": float(loss),
         }

@@ -138,8 +138,9 @@ int lse_segment_sum_rows(const float *rows, int32_t width, const int64_t *packed
  * (R:lse_nerf/lse_field.py:298-300, 306-310, 347-356; SH of tcnn, degree 4). emb_table NULL -> zeros. */
 int lse_ray_features_fwd(const float *rays_d, const float *emb_table, const int32_t *emb_idx, int32_t n_rays,
                          int32_t emb_dim, float *feat, lse_stream_t stream);
+/* d_rays_d[R,3] overwritten (nullable); d_emb_table[n_emb_rows, emb_dim] accumulate (nullable). */
 int lse_ray_features_bwd(const float *rays_d, const float *d_feat, const int32_t *emb_idx, int32_t n_rays,
-                         int32_t emb_dim, float *d_rays_d, float *d_emb_table, lse_stream_t stream);
+                         int32_t emb_dim, int32_t n_emb_rows, float *d_rays_d, float *d_emb_table, lse_stream_t stream);
 /* small dense helpers on per-ray matrices: y[R,M] = x[R,K] W[M,K]^T ; dx[R,K] = dy[R,M] W[M,K] ;
  * dW[M,K] += dy^T x. */
 int lse_linear_fwd(const float *w, const float *x, int32_t rows, int32_t m, int32_t k, float *y, lse_stream_t stream);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
     "lse_segment_sum_rows": [P, I32, P, I32, P, P],
     "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],
-    "lse_ray_features_bwd": [P, P, P, I32, I32, P, P, P],
+    "lse_ray_features_bwd": [P, P, P, I32, I32, I32, P, P, P],
     "lse_linear_fwd": [P, P, I32, I32, I32, P, P],
     "lse_linear_bwd_input": [P, P, I32, I32, I32, P, P],
     "lse_gemm_tn_acc": [P, I32, P, I32, I32, I64, P, I32, P],

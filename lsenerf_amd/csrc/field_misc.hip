@@ -230,9 +230,26 @@ __global__ __launch_bounds__(256) void ray_features_bwd_kernel(const float *__re
         // d v / d dir = (1/2)*2 = 1
         d_dirs[r * 3 + 0] = gx; d_dirs[r * 3 + 1] = gy; d_dirs[r * 3 + 2] = gz;
     }
-    if (d_emb && eidx) {
-        const int64_t e = eidx[r];
-        for (int k = 0; k < emb_dim && k < 32; ++k) atomicAdd(&d_emb[e * emb_dim + k], g[31 + k]);
+}
+
+// d(embedding row e) = sum over the rays that use row e.  All samples of a ray share one row and a batch uses only a
+// handful of rows, so atomics would pile onto a few addresses (14x slower per MI355X_MICROARCH.md "contention");
+// instead one workgroup per embedding row scans the ray list (R is a few thousand) and reduces in LDS.
+__global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__ dfeat, const int32_t *__restrict__ eidx,
+                                                       int n_rays, int emb_dim, float *__restrict__ d_emb)
+{
+    __shared__ float red[8][32];
+    const int e = blockIdx.x, col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    float acc = 0.f;
+    for (int r = part; r < n_rays; r += 8)
+        if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * 64 + 31 + col];
+    red[part][col] = acc;
+    __syncthreads();
+    if (part == 0 && col < emb_dim) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += red[p][col];
+        d_emb[(int64_t)e * emb_dim + col] += s;
     }
 }
 
@@ -320,13 +337,19 @@ extern "C" int lse_ray_features_fwd(const float *rays_d, const float *emb_table,
 }
 
 extern "C" int lse_ray_features_bwd(const float *rays_d, const float *d_feat, const int32_t *emb_idx, int32_t n_rays,
-                                    int32_t emb_dim, float *d_rays_d, float *d_emb_table, lse_stream_t stream)
+                                    int32_t emb_dim, int32_t n_emb_rows, float *d_rays_d, float *d_emb_table,
+                                    lse_stream_t stream)
 {
     LSE_REQUIRE(n_rays >= 0, "lse_ray_features_bwd: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(rays_d && d_feat, "lse_ray_features_bwd: null pointer");
     LSE_REQUIRE(emb_dim == 0 || emb_dim == 32, "lse_ray_features_bwd: emb_dim must be 0 or 32 (got %d)", emb_dim);
-    hipLaunchKernelGGL(ray_features_bwd_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, lse::as_stream(stream), rays_d,
-                       d_feat, emb_idx, n_rays, emb_dim, d_rays_d, d_emb_table);
+    LSE_REQUIRE(!d_emb_table || n_emb_rows > 0, "lse_ray_features_bwd: d_emb_table needs n_emb_rows");
+    if (d_rays_d)
+        hipLaunchKernelGGL(ray_features_bwd_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, lse::as_stream(stream),
+                           rays_d, d_feat, emb_idx, n_rays, emb_dim, d_rays_d, d_emb_table);
+    if (d_emb_table && emb_idx && emb_dim > 0)
+        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows), dim3(256), 0, lse::as_stream(stream), d_feat, emb_idx, n_rays,
+                           emb_dim, d_emb_table);
     return lse::check_launch("lse_ray_features_bwd");
 }

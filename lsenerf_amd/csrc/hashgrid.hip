@@ -11,8 +11,8 @@
 //   * forward: one (level, sample-chunk) per workgroup with the level chosen from blockIdx % 8.  Workgroups
 //     are dealt round-robin over the 8 XCDs, so each XCD's private 4 MiB L2 only ever sees 1/8 of the levels
 //     (2 of 16) instead of the whole 48.8 MB table.  Placement affects speed only, never results.
-//   * backward: one lane per sample walks all levels so d(x) accumulates in registers; table gradients are
-//     f32 global atomics (memory-side on gfx950, so no level/XCD affinity is attempted there).
+//   * backward: 16 lanes per sample (one per corner x feature) with run-length pre-accumulation, see hash_bwd_kernel;
+//     table gradients are f32 global atomics (memory-side on gfx950, so no level/XCD affinity is attempted there).
 #include "common.h"
 
 namespace {
@@ -132,68 +132,100 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
     }
 }
 
+// Backward.  Lane mapping: 16 lanes per sample -- lane k of a 16-lane group owns (corner k>>1, feature k&1) -- and each
+// group walks 16 CONSECUTIVE samples of the ray (one per round).  Consequences:
+//   * one atomic wave-instruction covers 4 samples x 8 corners x 2 features: the two features of an entry and the
+//     x / x+1 corner pair are neighbouring dwords, so the instruction touches ~18 64-byte lines instead of 64
+//     (memory-side float atomics are priced per line request, MI355X_MICROARCH.md "Global float atomics");
+//   * consecutive samples of a ray stay in the same cell at the coarse and middle levels: each lane run-length
+//     accumulates (index, sum) in registers and only issues an atomic when its entry index changes;
+//   * d(x) partial products are kept per round in registers and reduced over the 16 lanes once, after all levels.
 template <bool WITH_DX>
 __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float *__restrict__ x,
-                                                       const float2 *__restrict__ dy,
-                                                       const float2 *__restrict__ table, float *__restrict__ dtable,
+                                                       const float *__restrict__ dy,
+                                                       const float *__restrict__ table, float *__restrict__ dtable,
                                                        float *__restrict__ dx, int64_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x0 = x[i * 3 + 0], x1 = x[i * 3 + 1], x2 = x[i * 3 + 2];
-    float gx = 0.f, gy = 0.f, gz = 0.f;
+    constexpr int kRounds = 16;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
+    const int corner = k >> 1, f = k & 1;
+    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const int64_t sb = wave_base + grp * kRounds;     // first sample of this 16-lane group
+    if (wave_base >= n) return;
+
+    float xs[kRounds][3];
+    bool valid[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int64_t i = sb + r;
+        valid[r] = i < n;
+        const int64_t ii = valid[r] ? i : n - 1;
+        xs[r][0] = x[ii * 3 + 0];
+        xs[r][1] = x[ii * 3 + 1];
+        xs[r][2] = x[ii * 3 + 2];
+    }
+    float dxp[kRounds][3];
+    if (WITH_DX) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) dxp[r][0] = dxp[r][1] = dxp[r][2] = 0.f;
+    }
+    const uint32_t cx = corner & 1, cy = (corner >> 1) & 1, cz = (corner >> 2) & 1;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+
     for (int l = 0; l < g.n_levels; ++l) {
         const LevelInfo li = level_info(g, l);
-        float w[3];
-        uint32_t p[3];
-        pos_fract(x0, li.scale, w[0], p[0]);
-        pos_fract(x1, li.scale, w[1], p[1]);
-        pos_fract(x2, li.scale, w[2], p[2]);
-        const float2 gyl = dy[(int64_t)l * n + i];
-        uint32_t idx[8];
+        float *__restrict__ dt = dtable + 2 * (size_t)li.offset + f;
+        const float *__restrict__ tab = WITH_DX ? table + 2 * (size_t)li.offset + f : nullptr;
+        const float *__restrict__ dyl = dy + 2 * (size_t)l * n + f;
+        uint32_t cur = kNone;
+        float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            idx[c] = grid_index(li, p[0] + (c & 1), p[1] + ((c >> 1) & 1), p[2] + ((c >> 2) & 1));
-        float dot[8];
-        if (WITH_DX) {
-            const float2 *__restrict__ tab = table + li.offset;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float2 v = tab[idx[c]];
-                dot[c] = v.x * gyl.x + v.y * gyl.y;
+        for (int r = 0; r < kRounds; ++r) {
+            float w0, w1, w2;
+            uint32_t p0, p1, p2;
+            pos_fract(xs[r][0], li.scale, w0, p0);
+            pos_fract(xs[r][1], li.scale, w1, p1);
+            pos_fract(xs[r][2], li.scale, w2, p2);
+            const uint32_t idx = valid[r] ? grid_index(li, p0 + cx, p1 + cy, p2 + cz) : kNone;
+            const float sx = cx ? w0 : 1.f - w0, sy = cy ? w1 : 1.f - w1, sz = cz ? w2 : 1.f - w2;
+            const int64_t ii = valid[r] ? sb + r : n - 1;
+            const float gy = dyl[2 * ii];
+            const float v = sx * sy * sz * gy;
+            if (idx == cur) {
+                acc += v;
+            } else {
+                if (cur != kNone) atomicAdd(dt + 2 * (size_t)cur, acc);
+                cur = idx;
+                acc = v;
+            }
+            if (WITH_DX) {
+                const float tv = valid[r] ? tab[2 * (size_t)idx] : 0.f;
+                const float t = li.scale * gy * tv;
+                dxp[r][0] = fmaf(t * (cx ? 1.f : -1.f), sy * sz, dxp[r][0]);
+                dxp[r][1] = fmaf(t * (cy ? 1.f : -1.f), sx * sz, dxp[r][1]);
+                dxp[r][2] = fmaf(t * (cz ? 1.f : -1.f), sx * sy, dxp[r][2]);
             }
         }
-        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float wt = 1.f;
-            wt *= (c & 1) ? w[0] : 1.f - w[0];
-            wt *= (c & 2) ? w[1] : 1.f - w[1];
-            wt *= (c & 4) ? w[2] : 1.f - w[2];
-            atomicAdd(dt + 2 * (size_t)idx[c] + 0, wt * gyl.x);
-            atomicAdd(dt + 2 * (size_t)idx[c] + 1, wt * gyl.y);
-        }
-        if (WITH_DX) {
-            // d y / d x_d = scale * sum over the 4 edges along d of w_other * (v(p+e_d) - v(p))
-            const float wx[2] = {1.f - w[0], w[0]}, wy[2] = {1.f - w[1], w[1]}, wz[2] = {1.f - w[2], w[2]};
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    sx += wy[b] * wz[c] * (dot[1 + 2 * b + 4 * c] - dot[0 + 2 * b + 4 * c]);
-                    sy += wx[b] * wz[c] * (dot[b + 2 + 4 * c] - dot[b + 0 + 4 * c]);
-                    sz += wx[b] * wy[c] * (dot[b + 2 * c + 4] - dot[b + 2 * c + 0]);
-                }
-            gx = fmaf(li.scale, sx, gx);
-            gy = fmaf(li.scale, sy, gy);
-            gz = fmaf(li.scale, sz, gz);
-        }
+        if (cur != kNone) atomicAdd(dt + 2 * (size_t)cur, acc);
     }
     if (WITH_DX) {
-        dx[i * 3 + 0] = gx;
-        dx[i * 3 + 1] = gy;
-        dx[i * 3 + 2] = gz;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = dxp[r][d];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                dxp[r][d] = v;
+            }
+            if (k == 0 && valid[r]) {
+                dx[(sb + r) * 3 + 0] = dxp[r][0];
+                dx[(sb + r) * 3 + 1] = dxp[r][1];
+                dx[(sb + r) * 3 + 2] = dxp[r][2];
+            }
+        }
     }
 }
 
@@ -246,10 +278,10 @@ extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const f
     const int64_t blocks = (n + 255) / 256;
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
     if (dx)
-        hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01,
-                           reinterpret_cast<const float2 *>(dy), reinterpret_cast<const float2 *>(table), dtable, dx, n);
+        hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01, dy,
+                           table, dtable, dx, n);
     else
-        hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01,
-                           reinterpret_cast<const float2 *>(dy), nullptr, dtable, dx, n);
+        hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01, dy,
+                           (const float *)nullptr, dtable, dx, n);
     return lse::check_launch("lse_hash_bwd");
 }

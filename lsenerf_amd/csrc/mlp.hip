@@ -550,6 +550,7 @@ int gemm_tn_dispatch(const float *g, int m, const float *a, int k, int al, int64
     CASE(64, 32, LSE_IN_ROWMAJOR);
     CASE(64, 64, LSE_IN_ROWMAJOR);
     CASE(32, 16, LSE_IN_ROWMAJOR);
+    CASE(32, 64, LSE_IN_ROWMAJOR);
     CASE(32, 32, LSE_IN_ROWMAJOR);
     CASE(16, 64, LSE_IN_ROWMAJOR);
     CASE(16, 32, LSE_IN_ROWMAJOR);

@@ -375,7 +375,8 @@ class _RayFeaturesFn(torch.autograd.Function):
         d_dirs = torch.empty_like(rays_d) if ctx.needs_input_grad[0] else None
         d_emb = torch.zeros_like(emb_table) if (emb_table is not None and ctx.needs_input_grad[1]) else None
         _lib.call("lse_ray_features_bwd", _f32(rays_d, "rays_d"), _f32(d_feat, "d_feat"),
-                  _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim, _f32(d_dirs, "d_dirs", True),
+                  _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim,
+                  0 if emb_table is None else emb_table.shape[0], _f32(d_dirs, "d_dirs", True),
                   _f32(d_emb, "d_emb", True), _stream())
         return d_dirs, d_emb, None
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# One GPU-box round: parity tests, smoke, bench, rocprofv3 kernel stats.  Usage: tools/gpu_round.sh <tag> [pytest-args]
+TAG=${1:-r}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+timeout -k 10 700 python -m pytest tests -m gpu -q --timeout 240 "$@" > $OUT/pytest.log 2>&1; rc=$?
+echo "pytest rc=$rc"; tail -4 $OUT/pytest.log
+if [ $rc -ge 124 ]; then echo "pytest killed; stopping"; exit $rc; fi
+timeout -k 10 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; rc=$?; echo "smoke rc=$rc"; tail -2 $OUT/smoke.log
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 600 python bench.py > $OUT/bench.log 2>&1; rc=$?; echo "bench rc=$rc"; tail -3 $OUT/bench.log | cut -c1-1800
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1; rc=$?
+echo "rocprof rc=$rc"; find $OUT/prof -name "*kernel_stats*" | head
