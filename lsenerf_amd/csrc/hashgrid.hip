@@ -14,6 +14,7 @@
 //   * backward: 16 lanes per sample (one per corner x feature) with run-length pre-accumulation, see hash_bwd_kernel;
 //     table gradients are f32 global atomics (memory-side on gfx950, so no level/XCD affinity is attempted there).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,13 +77,21 @@ constexpr int kFwdItems = 4;   // samples per lane -> 32 independent gathers in 
 
 __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, const float *__restrict__ x,
                                                                const float2 *__restrict__ table,
-                                                               float2 *__restrict__ y, int64_t n)
+                                                               float2 *__restrict__ y, int64_t n, int64_t chunks,
+                                                               int mapping)
 {
     const int L = g.n_levels;
     int level;
     int64_t chunk;
     const int bid = blockIdx.x;
-    if ((L & 7) == 0) {   // XCD-affine: blockIdx % 8 fixes the level residue class
+    if ((L & 7) == 0 && mapping == 0) {
+        // XCD-affine AND level-sequential: blockIdx % 8 fixes the level residue class, and because workgroups are
+        // dispatched in order, each XCD finishes all chunks of one level before starting its next one, so its 4 MiB
+        // L2 holds one 4 MB level table at a time.
+        const int64_t slot = bid >> 3;
+        level = (bid & 7) + 8 * (int)(slot / chunks);
+        chunk = slot % chunks;
+    } else if ((L & 7) == 0 && mapping == 1) {   // XCD-affine, levels interleaved (A/B reference)
         const int per = L >> 3;
         const int slot = bid >> 3;
         level = (bid & 7) + 8 * (slot % per);
@@ -260,8 +269,9 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     const int64_t chunks = (n + kFwdThreads * kFwdItems - 1) / (kFwdThreads * kFwdItems);
     const int64_t blocks = chunks * g.n_levels;
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
+    static const int mapping = getenv("LSE_HASH_FWD_MAPPING") ? atoi(getenv("LSE_HASH_FWD_MAPPING")) : 0;
     hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, lse::as_stream(stream), g, x01,
-                       reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n);
+                       reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping);
     return lse::check_launch("lse_hash_fwd");
 }
 

@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int kMaxLevels = LSE_MAX_OCC_LEVELS;
+constexpr int kBatch = 16;   // DDA cells looked ahead per batch (occupancy loads in flight)
 
 struct TraverseArgs {
     const float *rays_o, *rays_d;
@@ -161,56 +162,79 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             ovf[k] = fin + stp[k];
         }
 
-        for (; budget > 0; --budget) {
-            float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
-            t_traverse = fminf(t_traverse, this_tmax);
-            const int64_t cell = (int64_t)cur[0] * a.ry * a.rz + (int64_t)cur[1] * a.rz + cur[2] +
-                                 (int64_t)level * cells_per_level;
-            if (!a.binaries[cell]) {
-                if (a.step_size <= 0.0f) {
-                    t_last = t_traverse;
-                } else {
-                    for (; budget > 0; --budget) {
-                        const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
-                        if (t_last + dt * 0.5f >= t_traverse) break;
-                        t_last += dt;
-                    }
-                }
-                continuous = false;
-            } else {
-                for (; budget > 0; --budget) {
-                    float t_next;
-                    if (a.step_size <= 0.0f) {
-                        t_next = t_traverse;
+        // The DDA cell sequence does not depend on the marching, so it is run ahead in batches of kBatch cells with all
+        // occupancy loads in flight at once (each is a dependent ~1 us HBM/MALL access when done one by one); the
+        // marching then consumes the batch in order.  Same arithmetic, same order of float operations as upstream.
+        bool seg_alive = true;
+        while (seg_alive && budget > 0) {
+            float tt[kBatch];
+            uint8_t oc[kBatch];
+            int nb = 0;
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                if (seg_alive) {
+                    float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                    t_traverse = fminf(t_traverse, this_tmax);
+                    const int64_t cell = (int64_t)cur[0] * a.ry * a.rz + (int64_t)cur[1] * a.rz + cur[2] +
+                                         (int64_t)level * cells_per_level;
+                    tt[b] = t_traverse;
+                    oc[b] = a.binaries[cell];
+                    nb = b + 1;
+                    // step to the neighbour cell (ties: x only if strictly smallest, then y, else z)
+                    bool alive = true;
+                    if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
+                        cur[0] += stp[0]; tdist[0] += delta[0]; alive = cur[0] != ovf[0];
+                    } else if (tdist[1] < tdist[2]) {
+                        cur[1] += stp[1]; tdist[1] += delta[1]; alive = cur[1] != ovf[1];
                     } else {
-                        const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
-                        if (t_last + dt * 0.5f >= t_traverse) break;
-                        t_next = t_last + dt;
+                        cur[2] += stp[2]; tdist[2] += delta[2]; alive = cur[2] != ovf[2];
                     }
-                    if (WRITE) {
-                        a.ray_indices[base + n_samples] = tid;
-                        a.t_starts[base + n_samples] = t_last;
-                        a.t_ends[base + n_samples] = t_next;
-                    }
-                    n_samples++;
-                    continuous = true;
-                    t_last = t_next;
-                    if (t_next >= t_traverse) break;
+                    // leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read);
+                    // this implementation stops at the border (DESIGN.md "deviations").
+                    if (!alive || cur[0] < 0 || cur[0] >= a.rx || cur[1] < 0 || cur[1] >= a.ry || cur[2] < 0 ||
+                        cur[2] >= a.rz)
+                        seg_alive = false;
+                    --budget;
                 }
             }
-            // step to the neighbour cell (ties: x only if strictly smallest, then y, else z)
-            bool alive = true;
-            if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
-                cur[0] += stp[0]; tdist[0] += delta[0]; alive = cur[0] != ovf[0];
-            } else if (tdist[1] < tdist[2]) {
-                cur[1] += stp[1]; tdist[1] += delta[1]; alive = cur[1] != ovf[1];
-            } else {
-                cur[2] += stp[2]; tdist[2] += delta[2]; alive = cur[2] != ovf[2];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                if (b < nb) {
+                    const float t_traverse = tt[b];
+                    if (!oc[b]) {
+                        if (a.step_size <= 0.0f) {
+                            t_last = t_traverse;
+                        } else {
+                            for (; budget > 0; --budget) {
+                                const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
+                                if (t_last + dt * 0.5f >= t_traverse) break;
+                                t_last += dt;
+                            }
+                        }
+                        continuous = false;
+                    } else {
+                        for (; budget > 0; --budget) {
+                            float t_next;
+                            if (a.step_size <= 0.0f) {
+                                t_next = t_traverse;
+                            } else {
+                                const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
+                                if (t_last + dt * 0.5f >= t_traverse) break;
+                                t_next = t_last + dt;
+                            }
+                            if (WRITE) {
+                                a.ray_indices[base + n_samples] = tid;
+                                a.t_starts[base + n_samples] = t_last;
+                                a.t_ends[base + n_samples] = t_next;
+                            }
+                            n_samples++;
+                            continuous = true;
+                            t_last = t_next;
+                            if (t_next >= t_traverse) break;
+                        }
+                    }
+                }
             }
-            if (!alive) break;
-            // leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read);
-            // this implementation stops at the border (DESIGN.md "deviations").
-            if (cur[0] < 0 || cur[0] >= a.rx || cur[1] < 0 || cur[1] >= a.ry || cur[2] < 0 || cur[2] >= a.rz) break;
         }
     }
     if (!WRITE) a.chunk_cnts[tid] = n_samples;
