@@ -1,8 +1,12 @@
 // Occupancy-grid ray marching for gfx950: nerfacc 0.5.2 `traverse_grids` semantics as the reference consumes
 // them at R:lse_nerf/lse_grid_estimator.py:93-106 (t_starts = vals[is_left], t_ends = vals[is_right]).
 //
-// One lane per ray, one wave per workgroup (rays are few -- 4096 per GPU -- and each walks ~1e3 serial steps,
-// so the launch is spread over as many CUs as there are waves).  The slab tests against every level's AABB and
+// ONE RAY PER WAVE: the march is a serial float chain per ray (each sample edge is the previous one plus dt, and that
+// exact sequence of roundings is part of the bit-exact contract), so the kernel is bound by instruction issue along that
+// chain, not by lanes.  Giving every ray its own wave makes the ray index wave-uniform (blockIdx.x): the compiler emits
+// scalar loads and scalar branches (no exec-mask bookkeeping, which tripled the instruction count of a lane-per-ray
+// version), 4096 rays become 4 waves on every SIMD of the chip, and the otherwise idle lanes fetch the look-ahead
+// batch's occupancy bytes in one load + ballot.  The slab tests against every level's AABB and
 // the boundary sort are folded into the prologue (upstream: a separate kernel + torch.sort).  Samples are
 // emitted as (t_last, t_next) pairs, which is exactly what the is_left/is_right mask extraction yields.
 //
@@ -10,6 +14,7 @@
 // edges must be bit-identical to the strict-fp32 CPU oracle, so every multiply/add rounds separately and every
 // division is IEEE-correct.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +38,14 @@ struct TraverseArgs {
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
 {
     return fminf(fmaxf(t * cone_angle, dt_min), dt_max);
+}
+
+// cone_angle == 0 and 0 < step <= 1e10: clamp(t*0, step, 1e10) == step bit for bit for every finite t, so the
+// three-instruction clamp leaves the serial chain (host picks the instantiation).
+template <bool CONST_DT>
+__device__ __forceinline__ float calc_dt_t(float t, float cone_angle, float dt_min, float dt_max)
+{
+    return CONST_DT ? dt_min : calc_dt(t, cone_angle, dt_min, dt_max);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -60,10 +73,13 @@ __device__ bool slab(const float o[3], const float inv[3], const float *__restri
     return true;
 }
 
-template <bool WRITE>
+template <bool WRITE, bool CONST_DT>
 __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_tt[kBatch];
+    __shared__ int s_cell[kBatch];
+    const int tid = blockIdx.x;          // wave-uniform ray index
+    const int lane = threadIdx.x;
     if (tid >= a.n_rays) return;
     const float eps = 1e-6f;
     const int L = a.levels;
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
     float t_last = ray_tmin;
     bool continuous = false;
     const int res[3] = {a.rx, a.ry, a.rz};
-    const int64_t cells_per_level = (int64_t)a.rx * a.ry * a.rz;
+    const int cells_per_level = a.rx * a.ry * a.rz;   // levels*cells < 2^31 is checked on the host
 
     for (int i = 0; i < 2 * L - 1; ++i) {
         const bool entering = order[i] < L;
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 t_last = this_tmin;
             } else {
                 for (; budget > 0; --budget) {
-                    const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
+                    const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
                     if (t_last + dt * 0.5f >= this_tmin) break;
                     t_last += dt;
                 }
@@ -165,79 +181,91 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
         // The DDA cell sequence does not depend on the marching, so it is run ahead in batches of kBatch cells with all
         // occupancy loads in flight at once (each is a dependent ~1 us HBM/MALL access when done one by one); the
         // marching then consumes the batch in order.  Same arithmetic, same order of float operations as upstream.
+        // Code size matters here: one wave per SIMD walks this loop nest, so it must stay resident in the instruction
+        // cache -- the batch lives in LDS (per-lane slots) + a 16-bit occupancy mask, and every phase is a small
+        // dynamic loop with ONE copy of the marching code.
         bool seg_alive = true;
         while (seg_alive && budget > 0) {
-            float tt[kBatch];
-            uint8_t oc[kBatch];
             int nb = 0;
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                if (seg_alive) {
-                    float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
-                    t_traverse = fminf(t_traverse, this_tmax);
-                    const int64_t cell = (int64_t)cur[0] * a.ry * a.rz + (int64_t)cur[1] * a.rz + cur[2] +
-                                         (int64_t)level * cells_per_level;
-                    tt[b] = t_traverse;
-                    oc[b] = a.binaries[cell];
-                    nb = b + 1;
-                    // step to the neighbour cell (ties: x only if strictly smallest, then y, else z)
-                    bool alive = true;
-                    if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
-                        cur[0] += stp[0]; tdist[0] += delta[0]; alive = cur[0] != ovf[0];
-                    } else if (tdist[1] < tdist[2]) {
-                        cur[1] += stp[1]; tdist[1] += delta[1]; alive = cur[1] != ovf[1];
-                    } else {
-                        cur[2] += stp[2]; tdist[2] += delta[2]; alive = cur[2] != ovf[2];
-                    }
-                    // leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read);
-                    // this implementation stops at the border (DESIGN.md "deviations").
-                    if (!alive || cur[0] < 0 || cur[0] >= a.rx || cur[1] < 0 || cur[1] >= a.ry || cur[2] < 0 ||
-                        cur[2] >= a.rz)
-                        seg_alive = false;
-                    --budget;
+            for (int b = 0; b < kBatch && seg_alive; ++b) {
+                float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                t_traverse = fminf(t_traverse, this_tmax);
+                s_tt[b] = t_traverse;          // every lane writes the same (uniform) value
+                s_cell[b] = (cur[0] * a.ry + cur[1]) * a.rz + cur[2] + level * cells_per_level;
+                nb = b + 1;
+                // step to the neighbour cell (ties: x only if strictly smallest, then y, else z)
+                bool alive = true;
+                if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
+                    cur[0] += stp[0]; tdist[0] += delta[0]; alive = cur[0] != ovf[0];
+                } else if (tdist[1] < tdist[2]) {
+                    cur[1] += stp[1]; tdist[1] += delta[1]; alive = cur[1] != ovf[1];
+                } else {
+                    cur[2] += stp[2]; tdist[2] += delta[2]; alive = cur[2] != ovf[2];
                 }
+                // leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read);
+                // this implementation stops at the border (DESIGN.md "deviations").
+                if (!alive || cur[0] < 0 || cur[0] >= a.rx || cur[1] < 0 || cur[1] >= a.ry || cur[2] < 0 || cur[2] >= a.rz)
+                    seg_alive = false;
+                --budget;
             }
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                if (b < nb) {
-                    const float t_traverse = tt[b];
-                    if (!oc[b]) {
-                        if (a.step_size <= 0.0f) {
-                            t_last = t_traverse;
-                        } else {
-                            for (; budget > 0; --budget) {
-                                const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
-                                if (t_last + dt * 0.5f >= t_traverse) break;
-                                t_last += dt;
-                            }
+            // lane b fetches the occupancy byte of look-ahead cell b: one load instruction for the whole batch
+            __syncthreads();
+            const bool my_occ = (lane < nb) ? (a.binaries[s_cell[lane]] != 0) : false;
+            const uint32_t occ_mask = (uint32_t)__ballot(my_occ);
+
+            // Flat marching loop: every iteration is either one marching step or one cell advance, chosen with
+            // selects instead of nested divergent loops (one backward branch per iteration).  It performs exactly the
+            // comparisons and additions of the published nested loops, in the same order.
+            if (a.step_size <= 0.0f) {
+                for (int b = 0; b < nb; ++b) {   // one interval per occupied cell
+                    const float t_traverse = s_tt[b];
+                    if ((occ_mask >> b) & 1u) {
+                        if (WRITE && lane == 0) {
+                            a.ray_indices[base + n_samples] = tid;
+                            a.t_starts[base + n_samples] = t_last;
+                            a.t_ends[base + n_samples] = t_traverse;
                         }
-                        continuous = false;
+                        n_samples++;
+                        continuous = true;
                     } else {
-                        for (; budget > 0; --budget) {
-                            float t_next;
-                            if (a.step_size <= 0.0f) {
-                                t_next = t_traverse;
-                            } else {
-                                const float dt = calc_dt(t_last, a.cone_angle, a.step_size, 1e10f);
-                                if (t_last + dt * 0.5f >= t_traverse) break;
-                                t_next = t_last + dt;
-                            }
-                            if (WRITE) {
+                        continuous = false;
+                    }
+                    t_last = t_traverse;
+                }
+            } else {
+                int b = 0;
+                float t_traverse = s_tt[0];
+                while (b < nb && budget > 0) {
+                    --budget;
+                    const bool occ = (occ_mask >> b) & 1u;
+                    const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
+                    const bool reached = t_last + dt * 0.5f >= t_traverse;
+                    bool cell_done = reached;
+                    if (!reached) {
+                        const float t_next = t_last + dt;
+                        if (occ) {
+                            if (WRITE && lane == 0) {
                                 a.ray_indices[base + n_samples] = tid;
                                 a.t_starts[base + n_samples] = t_last;
                                 a.t_ends[base + n_samples] = t_next;
                             }
                             n_samples++;
                             continuous = true;
-                            t_last = t_next;
-                            if (t_next >= t_traverse) break;
+                            cell_done = t_next >= t_traverse;
                         }
+                        t_last = t_next;
+                    }
+                    if (cell_done) {
+                        if (!occ) continuous = false;
+                        ++b;
+                        if (b < nb) t_traverse = s_tt[b];
                     }
                 }
             }
+            __syncthreads();   // the next batch overwrites the LDS slots
         }
     }
-    if (!WRITE) a.chunk_cnts[tid] = n_samples;
+    if (!WRITE && lane == 0) a.chunk_cnts[tid] = n_samples;
 }
 
 // single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
@@ -282,14 +310,22 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
     LSE_REQUIRE(levels >= 1 && levels <= LSE_MAX_OCC_LEVELS, "lse_traverse_grids: levels %d not in [1,%d]", levels,
                 LSE_MAX_OCC_LEVELS);
     LSE_REQUIRE(rx > 0 && ry > 0 && rz > 0, "lse_traverse_grids: bad resolution");
+    LSE_REQUIRE((int64_t)levels * rx * ry * rz < (1ll << 31), "lse_traverse_grids: grid too large (levels*cells >= 2^31)");
     LSE_REQUIRE(mode == 0 || mode == 1, "lse_traverse_grids: mode must be 0 (count) or 1 (write)");
     if (mode == 0) LSE_REQUIRE(chunk_cnts, "lse_traverse_grids: count pass needs chunk_cnts");
     if (mode == 1) LSE_REQUIRE(chunk_starts && ray_indices && t_starts && t_ends, "lse_traverse_grids: write pass needs outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
                    step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends};
-    const int blocks = (n_rays + 63) / 64;
-    if (mode == 0) hipLaunchKernelGGL(traverse_kernel<false>, dim3(blocks), dim3(64), 0, lse::as_stream(stream), a);
-    else hipLaunchKernelGGL(traverse_kernel<true>, dim3(blocks), dim3(64), 0, lse::as_stream(stream), a);
+    const int blocks = n_rays;   // one wave per ray
+    const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
+    hipStream_t st = lse::as_stream(stream);
+    if (mode == 0) {
+        if (const_dt) hipLaunchKernelGGL((traverse_kernel<false, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((traverse_kernel<false, false>), dim3(blocks), dim3(64), 0, st, a);
+    } else {
+        if (const_dt) hipLaunchKernelGGL((traverse_kernel<true, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((traverse_kernel<true, false>), dim3(blocks), dim3(64), 0, st, a);
+    }
     return lse::check_launch("lse_traverse_grids");
 }
 
