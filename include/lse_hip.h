@@ -123,11 +123,15 @@ int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, c
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations [n_hidden_layers][N][width]. */
 int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
                 const int32_t *row_bias_idx, float *out, float *act, int64_t n, lse_stream_t stream);
-/* backward data path: d_out[N,16] (w.r.t. activated output) -> d_out_pre[N,16], d_act[n_hidden_layers][N][width]
- * (w.r.t. pre-activations), d_in (layout of desc->in_layout; nullable). */
-int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *act, const float *out, const float *d_out,
-                float *d_out_pre, float *d_act, float *d_in, int64_t n, lse_stream_t stream);
-/* weight gradients, accumulate into d_params (same layout as params). */
+/* backward: d_out[N,16] (w.r.t. the activated output) -> d_in (layout of desc->in_layout; nullable) and, when d_params
+ * is given, the weight gradients of every layer accumulated into d_params (same layout as params) in the same pass
+ * (`in` = the layer-0 input is then required).  Optional outputs: d_out_pre[N,16], d_act[n_hidden_layers][N][width]
+ * (pre-activation gradients of every layer, what lse_mlp_wgrad consumes), d_act0[N][width] (layer 0 only: the
+ * row_bias gradient before the per-ray sum). */
+int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, const float *out,
+                const float *d_out, float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params,
+                int64_t n, lse_stream_t stream);
+/* unfused weight gradients from materialised d_act / d_out_pre, accumulate into d_params (same layout as params). */
 int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
                   const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream);
 /* out[R,width] += per-ray sum of d_act0[N,width] (gradient of row_bias). */

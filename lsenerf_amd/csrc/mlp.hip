@@ -15,6 +15,7 @@
 // fp32 MFMA runs at the fp32 VALU rate (157 TF peak): the win is register/issue economy and exact f32
 // (bitwise a k-ordered fmaf chain), which is what the reference's float32 tcnn build computes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,18 +45,22 @@ struct MlpArgs {
     int out_activation;
     // backward
     const float *d_out;
-    float *d_out_pre;
-    float *d_act;
-    float *d_in;
+    float *d_out_pre;   // nullable
+    float *d_act;       // nullable: all layers' pre-activation gradients (only the unfused wgrad path needs them)
+    float *d_act0;      // nullable: layer-0 pre-activation gradients only (row-bias gradient)
+    float *d_in;        // nullable
+    float *d_params;    // nullable: fused weight gradients accumulate here
 };
 
-constexpr int kCT = 4;   // column tiles (of 16 samples) per wave iteration -> 64 samples
+// CT = column tiles (of 16 samples) per wave iteration, NW = waves per workgroup (template parameters below).
+// (CT=4,NW=4): 64-sample tiles, fewest LDS weight reads per MFMA.  (CT=2,NW=8): half the registers -> 4 waves/SIMD,
+// which hides the first-touch HBM latency of the activation loads (the kernels are latency-, not MFMA-issue-bound).
 
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-template <int KIN, int WIDTH, int NHL, int INL>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
+template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(MlpArgs a)
 {
     constexpr int HB = WIDTH / 16, KS0 = KIN / 4, KSH = WIDTH / 4;
     constexpr int IMG0 = HB * KS0, IMGH = (NHL == 2) ? HB * KSH : 0, IMGO = KSH;
@@ -65,16 +70,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
     const float *W0 = a.params;
     const float *W1 = W0 + WIDTH * KIN;
     const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
-    for (int e = threadIdx.x; e < IMG0 * 64; e += 256) {
+    for (int e = threadIdx.x; e < IMG0 * 64; e += 64 * NW) {
         const int img = e >> 6, ln = e & 63, rb = img / KS0, ks = img % KS0, i = ln & 15, q = ln >> 4;
         img0[e] = W0[(16 * rb + i) * KIN + kidx_in<INL>(ks, q)];
     }
     if (NHL == 2)
-        for (int e = threadIdx.x; e < IMGH * 64; e += 256) {
+        for (int e = threadIdx.x; e < IMGH * 64; e += 64 * NW) {
             const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
             imgH[e] = W1[(16 * rb + i) * WIDTH + kidx_blk(ks, q)];
         }
-    for (int e = threadIdx.x; e < IMGO * 64; e += 256) {
+    for (int e = threadIdx.x; e < IMGO * 64; e += 64 * NW) {
         const int ks = e >> 6, ln = e & 63, i = ln & 15, q = ln >> 4;
         imgO[e] = Wo[i * WIDTH + kidx_blk(ks, q)];
     }
@@ -82,20 +87,21 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int64_t n = a.n;
-    const int64_t n_tiles = (n + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        int64_t s[kCT];
-        bool valid[kCT];
+    constexpr int TS = 16 * CT;   // samples per wave tile
+    const int64_t n_tiles = (n + TS - 1) / TS;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+        int64_t s[CT];
+        bool valid[CT];
 #pragma unroll
-        for (int ct = 0; ct < kCT; ++ct) {
-            const int64_t si = tile * 64 + ct * 16 + j;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int64_t si = tile * TS + ct * 16 + j;
             valid[ct] = si < n;
             s[ct] = valid[ct] ? si : n - 1;
         }
         // ---- layer-0 B operands: breg[ct][ks] = in[sample][kidx_in(ks, q)]
-        float breg[kCT][KS0];
+        float breg[CT][KS0];
 #pragma unroll
-        for (int ct = 0; ct < kCT; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             if (INL == LSE_IN_LEVELMAJOR) {
 #pragma unroll
                 for (int m = 0; m < KIN / 8; ++m) {
@@ -113,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
             }
         }
         // ---- layer 0
-        f32x4 h[HB][kCT];
+        f32x4 h[HB][CT];
         if (a.row_bias) {
 #pragma unroll
-            for (int ct = 0; ct < kCT; ++ct) {
+            for (int ct = 0; ct < CT; ++ct) {
                 const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[s[ct]] : s[ct];
 #pragma unroll
                 for (int rb = 0; rb < HB; ++rb)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) h[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct) h[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) {
@@ -134,13 +140,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
             for (int rb = 0; rb < HB; ++rb) {
                 const float aw = img0[(rb * KS0 + ks) * 64 + lane];
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) h[rb][ct] = LSE_MFMA(aw, breg[ct][ks], h[rb][ct]);
+                for (int ct = 0; ct < CT; ++ct) h[rb][ct] = LSE_MFMA(aw, breg[ct][ks], h[rb][ct]);
             }
         }
 #pragma unroll
         for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-            for (int ct = 0; ct < kCT; ++ct) {
+            for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h[rb][ct][r], 0.f);
                 if (a.act && valid[ct])
@@ -148,11 +154,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
             }
         // ---- hidden layer (width x width)
         if (NHL == 2) {
-            f32x4 h2[HB][kCT];
+            f32x4 h2[HB][CT];
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) h2[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int bp = 0; bp < HB; ++bp)
 #pragma unroll
@@ -162,14 +168,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
                     for (int rb = 0; rb < HB; ++rb) {
                         const float aw = imgH[(rb * KSH + ks) * 64 + lane];
 #pragma unroll
-                        for (int ct = 0; ct < kCT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
+                        for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
                     }
                 }
             float *act1 = a.act ? a.act + n * WIDTH : nullptr;
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) {
+                for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h2[rb][ct][r], 0.f);
                     if (act1 && valid[ct])
@@ -177,19 +183,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
                 }
         }
         // ---- output layer (16 x width)
-        f32x4 o[kCT];
+        f32x4 o[CT];
 #pragma unroll
-        for (int ct = 0; ct < kCT; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int bp = 0; bp < HB; ++bp)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float aw = imgO[(4 * bp + r) * 64 + lane];
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) o[ct] = LSE_MFMA(aw, h[bp][ct][r], o[ct]);
+                for (int ct = 0; ct < CT; ++ct) o[ct] = LSE_MFMA(aw, h[bp][ct][r], o[ct]);
             }
 #pragma unroll
-        for (int ct = 0; ct < kCT; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             if (a.out_activation == LSE_ACT_SIGMOID) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[ct][r] = 1.f / (1.f + __expf(-o[ct][r]));
@@ -200,32 +206,144 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward data path:  dOut -> dH_last -> (dH_0) -> dIn, all chained in registers with transposed A images
+// backward:  dOut -> dH_last -> (dH_0) -> dIn chained in registers with transposed A images, and (WGRAD) the weight
+// gradients of every layer in the same pass.
+//
+// Weight gradients need the SAMPLE index as the MFMA k dimension:  dW[m][k] += sum_s G[s][m] * A[s][k].
+//   * G (a gradient tile) and A (the saved activation tile, already loaded for the ReLU mask) both live in accumulator
+//     layout (sample on the lane, neuron on registers).  Each 16x16 (sample x neuron) block is transposed through a
+//     per-wave LDS buffer (row pitch 20 floats: conflict-free ds_write_b128, 4 ds_read_b32) into operand layout:
+//     lane (i,q) k-step t <- X[sample 4t+q][neuron i].  The layer-0 input is read in operand layout from memory.
+//   * the dW accumulator tiles stay in REGISTERS for the whole kernel (one wave per SIMD, 512-register budget:
+//     __launch_bounds__(256, 1)) and are flushed once per wave with global float atomics.  (An LDS-resident dW copy
+//     updated with ds_add_f32 was measured LDS-bound: ~190 LDS cycles per atomic wave-instruction.)
+// This removes the materialised d_act round trip and the separate G^T*A reduction launches.
 // ------------------------------------------------------------------------------------------------------
-template <int KIN, int WIDTH, int NHL, int INL>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
+constexpr int kTrPitch = 20;                 // floats per transposition-buffer row
+constexpr int kTrBlock = 16 * kTrPitch;      // one 16x16 block
+constexpr int kTrWave = 8 * kTrBlock;        // up to 4 + 4 blocks (G and A side) in flight per wave
+
+// in: v[mb] = block (rows 16mb..16mb+15 of G^T) for the 16 samples of one column tile, accumulator layout.
+// out: ga[mb][t] = A operand of k-step t (samples 4t..4t+3 of this column tile).
+template <int MB>
+__device__ __forceinline__ void transpose_to_a_operand(float *tr, const f32x4 (&v)[MB], float (&ga)[MB][4], int j, int q)
+{
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) *reinterpret_cast<f32x4 *>(tr + mb * kTrBlock + j * kTrPitch + 4 * q) = v[mb];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ga[mb][t] = tr[mb * kTrBlock + (4 * t + q) * kTrPitch + j];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// acc[MB][KB] (persistent 16x16 accumulator tiles of dW) += G^T A for one wave tile of 16*CT samples.
+//   G: MB row blocks x CT column tiles in accumulator layout (zero for invalid samples)  -> A operands via LDS transpose.
+//   A (two sources):
+//     wgrad_from_regs: A is also in accumulator layout (the activation tile loaded for the ReLU mask) -> B operands by
+//                      the same transpose (lane (j,q) k-step t <- A[sample 4t+q][column j]);
+//     wgrad_from_mem : A is the layer-0 input in memory, read in B-operand layout directly.
+template <int MB, int KB, int CT>
+__device__ __forceinline__ void wgrad_from_regs(f32x4 (&acc)[MB][KB], float *tr, const f32x4 (&G)[MB][CT],
+                                                const f32x4 (&A)[KB][CT], int j, int q)
+{
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4 gblk[MB], ablk[KB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) gblk[mb] = G[mb][ct];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) ablk[kb] = A[kb][ct];
+        float ga[MB][4], gb[KB][4];
+        transpose_to_a_operand<MB>(tr, gblk, ga, j, q);
+        transpose_to_a_operand<KB>(tr + MB * kTrBlock, ablk, gb, j, q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc[mb][kb] = LSE_MFMA(ga[mb][t], gb[kb][t], acc[mb][kb]);
+    }
+}
+
+template <int MB, int K, int AL, int CT>
+__device__ __forceinline__ void wgrad_from_mem(f32x4 (&acc)[MB][(K + 15) / 16], float *tr, const f32x4 (&G)[MB][CT],
+                                               const float *A, int64_t n, const int64_t tile_base, int j, int q)
+{
+    constexpr int KB = (K + 15) / 16;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        float gb[KB][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int64_t srow = tile_base + ct * 16 + 4 * t + q;
+            srow = srow < n ? srow : n - 1;          // G is zero there
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int col = 16 * kb + j;
+                float v = 0.f;
+                if (col < K) {
+                    if (AL == LSE_IN_LEVELMAJOR) v = A[((int64_t)(col >> 1) * n + srow) * 2 + (col & 1)];
+                    else v = A[srow * K + col];
+                }
+                gb[kb][t] = v;
+            }
+        }
+        f32x4 gblk[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) gblk[mb] = G[mb][ct];
+        float ga[MB][4];
+        transpose_to_a_operand<MB>(tr, gblk, ga, j, q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc[mb][kb] = LSE_MFMA(ga[mb][t], gb[kb][t], acc[mb][kb]);
+    }
+}
+
+// flush persistent accumulator tiles: D row = 4q + r -> m, col = j -> k
+template <int MB, int KB>
+__device__ __forceinline__ void flush_wgrad(float *dw, int ld, int k_real, const f32x4 (&acc)[MB][KB], int j, int q)
+{
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            if (16 * kb + j < k_real) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&dw[(16 * mb + 4 * q + r) * ld + 16 * kb + j], acc[mb][kb][r]);
+            }
+}
+
+template <int KIN, int WIDTH, int NHL, int INL, bool WGRAD, int CT, int NW>
+__global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bwd_kernel(MlpArgs a)
 {
     constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
     constexpr int RB0 = (KIN + 15) / 16;
     constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
+    constexpr int NP0 = WIDTH * KIN, NP1 = (NHL - 1) * WIDTH * WIDTH, NPO = 16 * WIDTH;
     extern __shared__ float lds[];
     float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
+    float *tr_all = imgI + IMGI * 64;                       // NW waves x kTrWave (WGRAD only)
 
     const float *W0 = a.params;
     const float *W1 = W0 + WIDTH * KIN;
     const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
     // dH_last^T = Wo^T (WIDTH x 16) * dOut^T : A[i][k] = Wo[k = 4q+ks][16rb+i]
-    for (int e = threadIdx.x; e < IMGO * 64; e += 256) {
+    for (int e = threadIdx.x; e < IMGO * 64; e += 64 * NW) {
         const int img = e >> 6, ln = e & 63, rb = img >> 2, ks = img & 3, i = ln & 15, q = ln >> 4;
         imgO[e] = Wo[(4 * q + ks) * WIDTH + 16 * rb + i];
     }
     if (NHL == 2)   // dH_0^T = W1^T * dH_1^T : A[i][k] = W1[kidx_blk(ks,q)][16rb+i]
-        for (int e = threadIdx.x; e < IMGH * 64; e += 256) {
+        for (int e = threadIdx.x; e < IMGH * 64; e += 64 * NW) {
             const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
             imgH[e] = W1[kidx_blk(ks, q) * WIDTH + 16 * rb + i];
         }
     if (a.d_in)     // dIn^T = W0^T (KIN x WIDTH) * dH_0^T : A[i][k] = W0[kidx_blk(ks,q)][16rb+i]
-        for (int e = threadIdx.x; e < IMGI * 64; e += 256) {
+        for (int e = threadIdx.x; e < IMGI * 64; e += 64 * NW) {
             const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
             const int col = 16 * rb + i;
             imgI[e] = col < KIN ? W0[kidx_blk(ks, q) * KIN + col] : 0.f;
@@ -233,57 +351,93 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    const int64_t n = a.n;
-    const int64_t n_tiles = (n + 63) / 64;
-    const float *act_last = a.act + (int64_t)(NHL - 1) * n * WIDTH;
-    float *dact_last = a.d_act + (int64_t)(NHL - 1) * n * WIDTH;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        int64_t s[kCT];
-        bool valid[kCT];
-        f32x4 g[kCT];
+    float *tr = tr_all + wave * kTrWave;
+    // persistent weight-gradient accumulators (WGRAD): dWo[16 x W], dW1[W x W], dW0[W x KIN]
+    constexpr int KB0 = (KIN + 15) / 16;
+    f32x4 accO[1][HB], acc1[(NHL == 2) ? HB : 1][(NHL == 2) ? HB : 1], acc0[HB][KB0];
+    if (WGRAD) {
 #pragma unroll
-        for (int ct = 0; ct < kCT; ++ct) {
-            const int64_t si = tile * 64 + ct * 16 + j;
+        for (int kb = 0; kb < HB; ++kb) accO[0][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < ((NHL == 2) ? HB : 1); ++mb)
+#pragma unroll
+            for (int kb = 0; kb < ((NHL == 2) ? HB : 1); ++kb) acc1[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t n = a.n;
+    constexpr int TS = 16 * CT;   // samples per wave tile
+    const int64_t n_tiles = (n + TS - 1) / TS;
+    const float *act_last = a.act + (int64_t)(NHL - 1) * n * WIDTH;
+    float *dact_last = a.d_act ? a.d_act + (int64_t)(NHL - 1) * n * WIDTH : nullptr;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+        const int64_t tile_base = tile * TS;
+        int64_t s[CT];
+        bool valid[CT];
+        f32x4 g[1][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int64_t si = tile_base + ct * 16 + j;
             valid[ct] = si < n;
             s[ct] = valid[ct] ? si : n - 1;
-            g[ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
+            g[0][ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
             if (a.out_activation == LSE_ACT_SIGMOID) {
                 const f32x4 ov = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[ct][r] = g[ct][r] * ov[r] * (1.f - ov[r]);
+                for (int r = 0; r < 4; ++r) g[0][ct][r] = g[0][ct][r] * ov[r] * (1.f - ov[r]);
             }
-            if (valid[ct]) *reinterpret_cast<f32x4 *>(a.d_out_pre + s[ct] * 16 + 4 * q) = g[ct];
+            if (!valid[ct]) g[0][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};   // tail columns contribute nothing downstream
+            if (a.d_out_pre && valid[ct]) *reinterpret_cast<f32x4 *>(a.d_out_pre + s[ct] * 16 + 4 * q) = g[0][ct];
         }
-        // ---- dH_last
-        f32x4 dh[HB][kCT];
+        // ---- saved activations of the last hidden layer (ReLU mask and, for WGRAD, the B side of dWo)
+        f32x4 hv[HB][CT];
 #pragma unroll
         for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-            for (int ct = 0; ct < kCT; ++ct) dh[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CT; ++ct)
+                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(act_last + s[ct] * WIDTH + 16 * rb + 4 * q);
+        // ---- output-layer weights: dWo[16 x WIDTH] += g^T * act_last
+        if (WGRAD) wgrad_from_regs<1, HB, CT>(accO, tr, g, hv, j, q);
+        // ---- dH_last
+        f32x4 dh[HB][CT];
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dh[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb) {
                 const float aw = imgO[(rb * 4 + r) * 64 + lane];
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) dh[rb][ct] = LSE_MFMA(aw, g[ct][r], dh[rb][ct]);
+                for (int ct = 0; ct < CT; ++ct) dh[rb][ct] = LSE_MFMA(aw, g[0][ct][r], dh[rb][ct]);
             }
 #pragma unroll
         for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-            for (int ct = 0; ct < kCT; ++ct) {
-                const f32x4 hv = *reinterpret_cast<const f32x4 *>(act_last + s[ct] * WIDTH + 16 * rb + 4 * q);
+            for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[r] > 0.f ? dh[rb][ct][r] : 0.f;
-                if (valid[ct]) *reinterpret_cast<f32x4 *>(dact_last + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[rb][ct][r] > 0.f ? dh[rb][ct][r] : 0.f;
+                if (valid[ct]) {
+                    if (dact_last) *reinterpret_cast<f32x4 *>(dact_last + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                    if (NHL == 1 && a.d_act0) *reinterpret_cast<f32x4 *>(a.d_act0 + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                }
             }
         // ---- dH_0 (two hidden layers)
         if (NHL == 2) {
-            f32x4 d0[HB][kCT];
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) d0[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct)
+                    hv[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q);
+            if constexpr (WGRAD && NHL == 2) wgrad_from_regs<HB, HB, CT>(acc1, tr, dh, hv, j, q);
+            f32x4 d0[HB][CT];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) d0[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int bp = 0; bp < HB; ++bp)
 #pragma unroll
@@ -293,26 +447,30 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
                     for (int rb = 0; rb < HB; ++rb) {
                         const float aw = imgH[(rb * KSH + ks) * 64 + lane];
 #pragma unroll
-                        for (int ct = 0; ct < kCT; ++ct) d0[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], d0[rb][ct]);
+                        for (int ct = 0; ct < CT; ++ct) d0[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], d0[rb][ct]);
                     }
                 }
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) {
-                    const f32x4 hv = *reinterpret_cast<const f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q);
+                for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[r] > 0.f ? d0[rb][ct][r] : 0.f;
-                    if (valid[ct]) *reinterpret_cast<f32x4 *>(a.d_act + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                    for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[rb][ct][r] > 0.f ? d0[rb][ct][r] : 0.f;
+                    if (valid[ct]) {
+                        if (a.d_act) *reinterpret_cast<f32x4 *>(a.d_act + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                        if (a.d_act0) *reinterpret_cast<f32x4 *>(a.d_act0 + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
+                    }
                 }
         }
+        // ---- layer-0 weights: dW0[WIDTH x KIN] += dH_0^T * in
+        if (WGRAD) wgrad_from_mem<HB, KIN, INL, CT>(acc0, tr, dh, a.in, n, tile_base, j, q);
         // ---- dIn
         if (a.d_in) {
-            f32x4 di[RB0][kCT];
+            f32x4 di[RB0][CT];
 #pragma unroll
             for (int rb = 0; rb < RB0; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) di[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct) di[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int bp = 0; bp < HB; ++bp)
 #pragma unroll
@@ -322,13 +480,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
                     for (int rb = 0; rb < RB0; ++rb) {
                         const float aw = imgI[(rb * KSH + ks) * 64 + lane];
 #pragma unroll
-                        for (int ct = 0; ct < kCT; ++ct) di[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], di[rb][ct]);
+                        for (int ct = 0; ct < CT; ++ct) di[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], di[rb][ct]);
                     }
                 }
 #pragma unroll
             for (int rb = 0; rb < RB0; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < kCT; ++ct) {
+                for (int ct = 0; ct < CT; ++ct) {
                     if (!valid[ct]) continue;
                     if (INL == LSE_IN_LEVELMAJOR) {
                         // rows 16rb+4q+r are features; feature f -> level f>>1, component f&1
@@ -344,6 +502,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(MlpArgs a)
                     }
                 }
         }
+    }
+    if (WGRAD) {
+        flush_wgrad<HB, KB0>(a.d_params, KIN, KIN, acc0, j, q);
+        if constexpr (NHL == 2) flush_wgrad<HB, HB>(a.d_params + NP0, WIDTH, WIDTH, acc1, j, q);
+        flush_wgrad<1, HB>(a.d_params + NP0 + NP1, WIDTH, WIDTH, accO, j, q);
     }
 }
 
@@ -477,26 +640,76 @@ int check_desc(const lse_mlp_desc *d, const char *who)
     return LSE_OK;
 }
 
-template <int KIN, int WIDTH, int NHL, int INL>
-int launch_fwd(const MlpArgs &a, hipStream_t st)
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
+int launch_fwd_cfg(const MlpArgs &a, hipStream_t st)
 {
     constexpr int HB = WIDTH / 16;
     constexpr int imgs = HB * (KIN / 4) + (NHL == 2 ? HB * (WIDTH / 4) : 0) + WIDTH / 4;
-    const int64_t tiles = (a.n + 63) / 64;
-    const int blocks = (int)std::min<int64_t>((tiles + 3) / 4, 2048);
-    hipLaunchKernelGGL((mlp_fwd_kernel<KIN, WIDTH, NHL, INL>), dim3(blocks), dim3(256), imgs * 256, st, a);
+    const int64_t tiles = (a.n + 16 * CT - 1) / (16 * CT);
+    const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 2048);
+    hipLaunchKernelGGL((mlp_fwd_kernel<KIN, WIDTH, NHL, INL, CT, NW>), dim3(blocks), dim3(64 * NW), imgs * 256, st, a);
     return lse::check_launch("lse_mlp_fwd");
+}
+
+template <int KIN, int WIDTH, int NHL, int INL>
+int launch_fwd(const MlpArgs &a, hipStream_t st)
+{
+    static const int cfg = env_int("LSE_MLP_FWD_CFG", 28);   // CT*10 + NW
+    switch (cfg) {
+    case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
+    case 216: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
+    case 116: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 1, 16>(a, st);
+    default: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
+    }
+}
+
+template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
+int launch_bwd_cfg(const MlpArgs &a, hipStream_t st)
+{
+    constexpr int HB = WIDTH / 16;
+    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4);
+    constexpr int n_params = WIDTH * KIN + (NHL - 1) * WIDTH * WIDTH + 16 * WIDTH;
+    const int64_t tiles = (a.n + 16 * CT - 1) / (16 * CT);
+    if (a.d_params) {
+        // one resident workgroup per CU (512-register waves); every wave flushes its dW accumulators once at the end
+        const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);
+        const size_t lds_bytes = imgs * 256 + (size_t)(NW * kTrWave) * sizeof(float);
+        (void)n_params;
+        static bool attr_set = false;   // per instantiation: allow more than the default 64 KiB of dynamic LDS
+        if (!attr_set && lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&mlp_bwd_kernel<KIN, WIDTH, NHL, INL, true, CT, NW>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) {
+                lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds_bytes, hipGetErrorString(e));
+                return LSE_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((mlp_bwd_kernel<KIN, WIDTH, NHL, INL, true, CT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
+    } else {
+        const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 2048);
+        hipLaunchKernelGGL((mlp_bwd_kernel<KIN, WIDTH, NHL, INL, false, CT, NW>), dim3(blocks), dim3(64 * NW), imgs * 256, st, a);
+    }
+    return lse::check_launch("lse_mlp_bwd");
 }
 
 template <int KIN, int WIDTH, int NHL, int INL>
 int launch_bwd(const MlpArgs &a, hipStream_t st)
 {
-    constexpr int HB = WIDTH / 16;
-    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4);
-    const int64_t tiles = (a.n + 63) / 64;
-    const int blocks = (int)std::min<int64_t>((tiles + 3) / 4, 2048);
-    hipLaunchKernelGGL((mlp_bwd_kernel<KIN, WIDTH, NHL, INL>), dim3(blocks), dim3(256), imgs * 256, st, a);
-    return lse::check_launch("lse_mlp_bwd");
+    static const int cfg = env_int("LSE_MLP_BWD_CFG", 28);   // CT*10 + NW
+    switch (cfg) {
+    case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
+    case 216: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
+    case 116: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 1, 16>(a, st);
+    default: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
+    }
 }
 
 #define LSE_MLP_DISPATCH(FN, d, a, st)                                                                   \
@@ -576,19 +789,21 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     LSE_MLP_DISPATCH(launch_fwd, desc, a, st);
 }
 
-extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *act, const float *out,
-                           const float *d_out, float *d_out_pre, float *d_act, float *d_in, int64_t n,
-                           lse_stream_t stream)
+extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act,
+                           const float *out, const float *d_out, float *d_out_pre, float *d_act, float *d_act0,
+                           float *d_in, float *d_params, int64_t n, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_bwd");
     if (rc) return rc;
     LSE_REQUIRE(n >= 0, "lse_mlp_bwd: n < 0");
     if (n == 0) return LSE_OK;
-    LSE_REQUIRE(params && act && d_out && d_out_pre && d_act, "lse_mlp_bwd: null pointer");
+    LSE_REQUIRE(params && act && d_out, "lse_mlp_bwd: null pointer");
     LSE_REQUIRE(desc->out_activation == LSE_ACT_NONE || out, "lse_mlp_bwd: sigmoid backward needs `out`");
+    LSE_REQUIRE(!d_params || in, "lse_mlp_bwd: fused weight gradients need the layer-0 input `in`");
     MlpArgs a{};
-    a.params = params; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
-    a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_in = d_in; a.n = n; a.out_activation = desc->out_activation;
+    a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
+    a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_act0 = d_act0; a.d_in = d_in; a.d_params = d_params; a.n = n;
+    a.out_activation = desc->out_activation;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
 }

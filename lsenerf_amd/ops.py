@@ -289,31 +289,40 @@ class _MlpFn(torch.autograd.Function):
         meta, n = ctx.meta, ctx.n
         dev = params.device
         d_out = _c(d_out)
-        d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        d_act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev)
+        need_bias = row_bias is not None and ctx.needs_input_grad[2]
+        d_act0 = torch.empty((n, meta.width), dtype=torch.float32, device=dev) if need_bias else None
         d_in = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        d_params = torch.zeros_like(params) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
-        _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(act, "act"), _f32(out, "out"),
-                  _f32(d_out, "d_out"), ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()),
-                  _f32(d_in, "d_in", True), n, _stream())
-        d_params = None
-        if ctx.needs_input_grad[0]:
-            d_params = torch.zeros_like(params)
+        if FUSED_WGRAD or d_params is None:
+            _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
+                      _f32(out, "out"), _f32(d_out, "d_out"), None, None, _f32(d_act0, "d_act0", True),
+                      _f32(d_in, "d_in", True), _f32(d_params, "d_params", True), n, _stream())
+        else:   # reference structure: materialise d_act, then one G^T A reduction per layer
+            d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
+            d_act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev)
+            _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
+                      _f32(out, "out"), _f32(d_out, "d_out"), ctypes.c_void_p(d_out_pre.data_ptr()),
+                      ctypes.c_void_p(d_act.data_ptr()), None, _f32(d_in, "d_in", True), None, n, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
                       ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
                       ctypes.c_void_p(d_params.data_ptr()), n, _stream())
+            d_act0 = d_act[0] if need_bias else None
         d_bias = None
-        if row_bias is not None and ctx.needs_input_grad[2]:
+        if need_bias:
             if row_bias_idx is None:
-                d_bias = d_act[0]
+                d_bias = d_act0
             elif bias_packed_info is not None:
                 d_bias = torch.zeros_like(row_bias)
-                _lib.call("lse_segment_sum_rows", ctypes.c_void_p(d_act.data_ptr()), meta.width,
+                _lib.call("lse_segment_sum_rows", ctypes.c_void_p(d_act0.data_ptr()), meta.width,
                           _chk(bias_packed_info, torch.int64, "bias_packed_info"), row_bias.shape[0],
                           ctypes.c_void_p(d_bias.data_ptr()), _stream())
             else:   # unsorted row indices: generic scatter-add (not on the hot path)
-                d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act[0])
+                d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act0)
         return d_params, d_in, d_bias, None, None, None, None
+
+
+FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 
 
 def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None):
