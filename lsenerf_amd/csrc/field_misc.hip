@@ -238,19 +238,15 @@ __global__ __launch_bounds__(256) void ray_features_bwd_kernel(const float *__re
 __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__ dfeat, const int32_t *__restrict__ eidx,
                                                        int n_rays, int emb_dim, float *__restrict__ d_emb)
 {
-    __shared__ float red[8][32];
-    const int e = blockIdx.x, col = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float acc = 0.f;
-    for (int r = part; r < n_rays; r += 8)
-        if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * 64 + 31 + col];
-    red[part][col] = acc;
+    __shared__ float red[32];
+    const int e = blockIdx.x;
+    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
     __syncthreads();
-    if (part == 0 && col < emb_dim) {
-        float s = 0.f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[p][col];
-        d_emb[(int64_t)e * emb_dim + col] += s;
-    }
+    for (int r = threadIdx.x; r < n_rays; r += 256)
+        if (eidx[r] == e)   // a few dozen rays per row: LDS atomics are fine here
+            for (int c = 0; c < emb_dim; ++c) atomicAdd(&red[c], dfeat[(int64_t)r * 64 + 31 + c]);
+    __syncthreads();
+    if ((int)threadIdx.x < emb_dim) d_emb[(int64_t)e * emb_dim + threadIdx.x] += red[threadIdx.x];
 }
 
 }  // namespace

@@ -50,6 +50,12 @@ struct MlpArgs {
     float *d_act0;      // nullable: layer-0 pre-activation gradients only (row-bias gradient)
     float *d_in;        // nullable
     float *d_params;    // nullable: fused weight gradients accumulate here
+    // fused density head (base MLP): sigma = density_scale * exp(out[:,0]) * selector
+    float *sigma_out;            // fwd, nullable
+    const uint8_t *selector;     // nullable (all in-bounds)
+    float density_scale;
+    const float *d_sigma;        // bwd, nullable: adds d_sigma * d(sigma)/d(out[:,0]) to the output gradient
+    int out_cols;                // 16 (padded row) or 4 (compact: only outputs 0..3 are stored / have gradients)
 };
 
 // CT = column tiles (of 16 samples) per wave iteration, NW = waves per workgroup (template parameters below).
@@ -200,7 +206,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[ct][r] = 1.f / (1.f + __expf(-o[ct][r]));
             }
-            if (valid[ct]) *reinterpret_cast<f32x4 *>(a.out + s[ct] * 16 + 4 * q) = o[ct];
+            if (valid[ct]) {
+                if (a.out_cols == 16) *reinterpret_cast<f32x4 *>(a.out + s[ct] * 16 + 4 * q) = o[ct];
+                else if (q == 0) *reinterpret_cast<f32x4 *>(a.out + s[ct] * 4) = o[ct];
+                if (a.sigma_out && q == 0) {   // trunc_exp density head on output 0 (R:lse_nerf/lse_field.py:286-287)
+                    const bool in_bounds = a.selector == nullptr || a.selector[s[ct]] != 0;
+                    a.sigma_out[s[ct]] = in_bounds ? a.density_scale * expf(o[ct][0]) : 0.f;
+                }
+            }
         }
     }
 }
@@ -382,11 +395,19 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
             const int64_t si = tile_base + ct * 16 + j;
             valid[ct] = si < n;
             s[ct] = valid[ct] ? si : n - 1;
-            g[0][ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
+            if (a.out_cols == 16) g[0][ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
+            else g[0][ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
             if (a.out_activation == LSE_ACT_SIGMOID) {
-                const f32x4 ov = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
+                f32x4 ov;
+                if (a.out_cols == 16) ov = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
+                else ov = (q == 0) ? *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g[0][ct][r] = g[0][ct][r] * ov[r] * (1.f - ov[r]);
+            }
+            if (a.d_sigma && q == 0) {   // trunc_exp backward: d out0 += d_sigma * scale * exp(clamp(out0, -15, 15)) * selector
+                const bool in_bounds = a.selector == nullptr || a.selector[s[ct]] != 0;
+                const float x0 = fminf(fmaxf(a.out[s[ct] * a.out_cols], -15.f), 15.f);
+                if (in_bounds) g[0][ct][0] += a.d_sigma[s[ct]] * a.density_scale * expf(x0);
             }
             if (!valid[ct]) g[0][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};   // tail columns contribute nothing downstream
             if (a.d_out_pre && valid[ct]) *reinterpret_cast<f32x4 *>(a.d_out_pre + s[ct] * 16 + 4 * q) = g[0][ct];
@@ -775,7 +796,8 @@ int gemm_tn_dispatch(const float *g, int m, const float *a, int k, int al, int64
 }  // namespace
 
 extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
-                           const int32_t *row_bias_idx, float *out, float *act, int64_t n, lse_stream_t stream)
+                           const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, float *sigma_out,
+                           const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_fwd");
     if (rc) return rc;
@@ -783,14 +805,17 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(params && in && out, "lse_mlp_fwd: null pointer");
     MlpArgs a{};
+    LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_fwd: out_cols must be 16 or 4");
     a.params = params; a.in = in; a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.out = out; a.act = act;
-    a.n = n; a.out_activation = desc->out_activation;
+    a.n = n; a.out_activation = desc->out_activation; a.out_cols = out_cols; a.sigma_out = sigma_out;
+    a.selector = selector; a.density_scale = density_scale;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_fwd, desc, a, st);
 }
 
 extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act,
-                           const float *out, const float *d_out, float *d_out_pre, float *d_act, float *d_act0,
+                           const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
+                           const uint8_t *selector, float density_scale, float *d_out_pre, float *d_act, float *d_act0,
                            float *d_in, float *d_params, int64_t n, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_bwd");
@@ -800,10 +825,14 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     LSE_REQUIRE(params && act && d_out, "lse_mlp_bwd: null pointer");
     LSE_REQUIRE(desc->out_activation == LSE_ACT_NONE || out, "lse_mlp_bwd: sigmoid backward needs `out`");
     LSE_REQUIRE(!d_params || in, "lse_mlp_bwd: fused weight gradients need the layer-0 input `in`");
+    LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_bwd: out_cols must be 16 or 4");
+    LSE_REQUIRE(!d_sigma || out, "lse_mlp_bwd: the density gradient needs `out`");
+    LSE_REQUIRE(out_cols == 16 || !d_out_pre, "lse_mlp_bwd: d_out_pre needs the padded 16-column layout");
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
     a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_act0 = d_act0; a.d_in = d_in; a.d_params = d_params; a.n = n;
-    a.out_activation = desc->out_activation;
+    a.out_activation = desc->out_activation; a.out_cols = out_cols; a.d_sigma = d_sigma; a.selector = selector;
+    a.density_scale = density_scale;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
 }

@@ -274,14 +274,14 @@ class LSEField(nn.Module):
         n = x01.shape[0]
         y = self.mlp_base_grid.forward_levelmajor(x01)
         mlp = self.mlp_base_mlp
+        dens = (sel, self.average_init_density)    # trunc_exp density head fused into the MLP epilogue / backward
         if mlp.in_pad == mlp.in_dim:
-            h = ops.fused_mlp(mlp.params, y, mlp.meta(), n)
+            h, sigma = ops.fused_mlp(mlp.params, y, mlp.meta(), n, density=dens)
         else:   # small grids (L*F < 16): tcnn's ones-padding columns act as a bias shared by every sample
             kparams, bias = mlp.split_padding()
             idx = torch.zeros(n, dtype=torch.int32, device=x01.device)
             seg = torch.tensor([[0, n]], dtype=torch.int64, device=x01.device)
-            h = ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg)
-        sigma = ops.density_from_mlp_out(h, sel, self.average_init_density)
+            h, sigma = ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg, density=dens)
         return sigma, h, sel
 
     def _head_params_split(self):
@@ -303,14 +303,14 @@ class LSEField(nn.Module):
     def rgb_packed(self, h: Tensor, rays_d: Tensor, emb_idx: Optional[Tensor], ray_idx: Optional[Tensor],
                    packed_info: Optional[Tensor], emb_table: Optional[Tensor]) -> Tensor:
         """Fast path of get_outputs: h[N,16] from ``density_packed``; per-ray directions/embedding ids.
-        Returns the padded head output [N,16] (columns 0..2 = RGB)."""
+        Returns the compact head output [N,4] (columns 0..2 = RGB)."""
         n = h.shape[0]
         feat = ops.ray_features(rays_d, emb_table, emb_idx)                 # [R,64]
         w_ray, kernel_params = self._head_params_split()
         row_bias = ops.linear(feat, w_ray)                                   # [R,W]
         meta = ops.MlpMeta(16, self.mlp_head.layer_width, self.mlp_head.n_hidden_layers, self.mlp_head.out_act,
                            _lib.LSE_IN_ROWMAJOR)
-        return ops.fused_mlp(kernel_params, h, meta, n, row_bias, ray_idx, packed_info)
+        return ops.fused_mlp(kernel_params, h, meta, n, row_bias, ray_idx, packed_info, out_cols=4)
 
     def _train_emb_table(self):
         if self.embedding_appearance is None:

@@ -270,40 +270,49 @@ def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> torch
 # ----------------------------------------------------------------------------------------------------
 class _MlpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, params, x, row_bias, row_bias_idx, bias_packed_info, meta: MlpMeta, n: int):
+    def forward(ctx, params, x, row_bias, row_bias_idx, bias_packed_info, selector, meta: MlpMeta, n: int, out_cols: int,
+                density_scale):
         dev = params.device
-        out = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        out = torch.empty((n, out_cols), dtype=torch.float32, device=dev)
+        sigma = torch.empty(n, dtype=torch.float32, device=dev) if density_scale is not None else None
         need_grad = any(t is not None and t.requires_grad for t in (params, x, row_bias))
         act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev) if need_grad else None
         desc = meta.desc()
         _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
                   _f32(row_bias, "row_bias", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True),
-                  ctypes.c_void_p(out.data_ptr()), _f32(act, "act", True), n, _stream())
-        ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info)
-        ctx.meta, ctx.n = meta, n
-        return out
+                  ctypes.c_void_p(out.data_ptr()), out_cols, _f32(act, "act", True), _f32(sigma, "sigma", True),
+                  _chk(selector, torch.uint8, "selector", True), float(density_scale or 0.0), n, _stream())
+        ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info, selector)
+        ctx.meta, ctx.n, ctx.out_cols, ctx.density_scale = meta, n, out_cols, density_scale
+        return out if sigma is None else (out, sigma)
 
     @staticmethod
-    def backward(ctx, d_out):
-        params, x, act, out, row_bias, row_bias_idx, bias_packed_info = ctx.saved_tensors
-        meta, n = ctx.meta, ctx.n
+    def backward(ctx, d_out, d_sigma=None):
+        params, x, act, out, row_bias, row_bias_idx, bias_packed_info, selector = ctx.saved_tensors
+        meta, n, out_cols = ctx.meta, ctx.n, ctx.out_cols
         dev = params.device
-        d_out = _c(d_out)
+        d_out = _c(d_out) if d_out is not None else torch.zeros((n, out_cols), dtype=torch.float32, device=dev)
+        d_sigma = _c(d_sigma) if d_sigma is not None else None
         need_bias = row_bias is not None and ctx.needs_input_grad[2]
         d_act0 = torch.empty((n, meta.width), dtype=torch.float32, device=dev) if need_bias else None
         d_in = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         d_params = torch.zeros_like(params) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
+        scale = float(ctx.density_scale or 0.0)
+        sel = _chk(selector, torch.uint8, "selector", True)
         if FUSED_WGRAD or d_params is None:
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
-                      _f32(out, "out"), _f32(d_out, "d_out"), None, None, _f32(d_act0, "d_act0", True),
-                      _f32(d_in, "d_in", True), _f32(d_params, "d_params", True), n, _stream())
-        else:   # reference structure: materialise d_act, then one G^T A reduction per layer
+                      _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
+                      None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
+                      _f32(d_params, "d_params", True), n, _stream())
+        else:   # reference structure: materialise d_act, then one G^T A reduction per layer (padded outputs only)
+            assert out_cols == 16
             d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
             d_act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev)
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
-                      _f32(out, "out"), _f32(d_out, "d_out"), ctypes.c_void_p(d_out_pre.data_ptr()),
-                      ctypes.c_void_p(d_act.data_ptr()), None, _f32(d_in, "d_in", True), None, n, _stream())
+                      _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
+                      ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()), None,
+                      _f32(d_in, "d_in", True), None, n, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
                       ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
                       ctypes.c_void_p(d_params.data_ptr()), n, _stream())
@@ -319,17 +328,20 @@ class _MlpFn(torch.autograd.Function):
                           ctypes.c_void_p(d_bias.data_ptr()), _stream())
             else:   # unsorted row indices: generic scatter-add (not on the hot path)
                 d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act0)
-        return d_params, d_in, d_bias, None, None, None, None
+        return d_params, d_in, d_bias, None, None, None, None, None, None, None
 
 
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 
 
-def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None):
-    """Bias-free fused MLP (tcnn layout).  Returns the padded output [n, 16].
+def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None,
+              out_cols: int = 16, density=None):
+    """Bias-free fused MLP (tcnn layout).  Returns the padded output [n, 16] (or the compact [n, 4] = outputs 0..3).
     ``row_bias[rows, width]`` is added to the layer-0 pre-activation of sample i from row ``row_bias_idx[i]``;
-    ``bias_packed_info[rows, 2]`` (start, count) must describe those rows' contiguous sample segments."""
-    return _MlpFn.apply(params, x, row_bias, row_bias_idx, bias_packed_info, meta, n)
+    ``bias_packed_info[rows, 2]`` (start, count) must describe those rows' contiguous sample segments.
+    ``density=(selector_or_None, scale)`` fuses the trunc_exp density head on output 0 and returns ``(out, sigma[n])``."""
+    selector, scale = (None, None) if density is None else density
+    return _MlpFn.apply(params, x, row_bias, row_bias_idx, bias_packed_info, selector, meta, n, out_cols, scale)
 
 
 # ----------------------------------------------------------------------------------------------------

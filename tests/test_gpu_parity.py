@@ -435,3 +435,48 @@ def test_errors_are_loud():
     meta = ops.MlpMeta(24, 64, 1)
     with pytest.raises(_lib.LseHipError):
         ops.fused_mlp(torch.rand(24 * 64 + 16 * 64).cuda(), torch.rand(8, 24).cuda(), meta, 8)
+
+
+def test_mlp_fused_density_head_and_compact_output():
+    """Base MLP with the trunc_exp density head fused (sigma + its gradient folded into output 0) and the head MLP with
+    the compact [N,4] output, against the oracle's separate ops."""
+    from oracle.field import TcnnMLP, trunc_exp
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    N = 3001
+    om = TcnnMLP(32, 2, 64, 16, None)
+    params = om.init_params(g)
+    x = torch.randn(N, 32, generator=g)
+    sel = torch.rand(N, generator=g) < 0.8
+    pc, xc = params.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    h_ref = om.forward(xc, pc)
+    h_ref_big = h_ref * torch.tensor([40.0] + [1.0] * 15)          # push some logits beyond the +-15 clamp of trunc_exp
+    sig_ref = 0.7 * trunc_exp(h_ref_big[:, 0]) * sel
+    meta = ops.MlpMeta(32, 64, 1, _lib.LSE_ACT_NONE, _lib.LSE_IN_LEVELMAJOR)
+    scale_w = torch.cat([torch.ones(64 * 32), torch.cat([torch.full((64,), 40.0), torch.ones(15 * 64)])])
+    pg = (params * scale_w).clone().cuda().requires_grad_(True)      # same effect: row 0 of W_out scaled by 40
+    xin = x.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda().requires_grad_(True)
+    h, sig = ops.fused_mlp(pg, xin, meta, N, density=(sel.cuda().to(torch.uint8), 0.7))
+    assert nmax_err(h, h_ref_big) < TOL_FWD and nmax_err(sig, sig_ref, 1e-3) < 5 * TOL_FWD
+    w1, w2 = torch.randn(N, 16, generator=g), torch.randn(N, generator=g) * 1e-3
+    ((h_ref_big * w1).sum() + (sig_ref * w2).sum()).backward()
+    ((h * w1.cuda()).sum() + (sig * w2.cuda()).sum()).backward()
+    assert nmax_err(pg.grad / scale_w.cuda(), pc.grad) < TOL_GRAD
+    assert nmax_err(xin.grad.permute(1, 0, 2).reshape(N, 32), xc.grad) < TOL_GRAD
+    # compact head output
+    oh = TcnnMLP(16, 3, 64, 3, "Sigmoid")
+    ph = oh.init_params(g)
+    xh = torch.randn(N, 16, generator=g)
+    phc, xhc = ph.clone().requires_grad_(True), xh.clone().requires_grad_(True)
+    rgb_ref = oh.forward(xhc, phc)
+    mh = ops.MlpMeta(16, 64, 2, _lib.LSE_ACT_SIGMOID, _lib.LSE_IN_ROWMAJOR)
+    phg, xhg = ph.clone().cuda().requires_grad_(True), xh.clone().cuda().requires_grad_(True)
+    out4 = ops.fused_mlp(phg, xhg, mh, N, out_cols=4)
+    assert out4.shape == (N, 4) and nmax_err(out4[:, :3], rgb_ref) < TOL_FWD
+    w3 = torch.randn(N, 3, generator=g)
+    (rgb_ref * w3).sum().backward()
+    (out4[:, :3] * w3.cuda()).sum().backward()
+    assert nmax_err(phg.grad[:64 * 16 + 64 * 64], phc.grad[:64 * 16 + 64 * 64]) < TOL_GRAD
+    assert nmax_err(phg.grad[64 * 16 + 64 * 64:][:3 * 64], phc.grad[64 * 16 + 64 * 64:][:3 * 64]) < TOL_GRAD
+    assert nmax_err(xhg.grad, xhc.grad) < TOL_GRAD
