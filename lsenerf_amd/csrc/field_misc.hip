@@ -238,15 +238,35 @@ __global__ __launch_bounds__(256) void ray_features_bwd_kernel(const float *__re
 __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__ dfeat, const int32_t *__restrict__ eidx,
                                                        int n_rays, int emb_dim, float *__restrict__ d_emb)
 {
-    __shared__ float red[32];
-    const int e = blockIdx.x;
-    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+    // thread (part, col): 8 ray-partitions x 32 columns; the ray-id test is wave-uniform per iteration (all 32 column
+    // lanes of a partition look at the same ray), partial sums stay in a register, one LDS pass combines the partitions.
+    __shared__ float red[8][32];
+    const int e = blockIdx.x, col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    float acc = 0.f;
+    // blockIdx.y splits the ray list further (more loads in flight chip-wide); partial sums meet in d_emb via atomics
+    const int nsplit = 8 * gridDim.y;
+    const int per = (n_rays + nsplit - 1) / nsplit;
+    const int r0 = min(n_rays, (blockIdx.y * 8 + part) * per), r1 = min(n_rays, r0 + per);
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {   // 4 independent id loads in flight
+        const int i0 = eidx[r], i1 = eidx[r + 1], i2 = eidx[r + 2], i3 = eidx[r + 3];
+        if (col < emb_dim) {
+            if (i0 == e) acc += dfeat[(int64_t)r * 64 + 31 + col];
+            if (i1 == e) acc += dfeat[(int64_t)(r + 1) * 64 + 31 + col];
+            if (i2 == e) acc += dfeat[(int64_t)(r + 2) * 64 + 31 + col];
+            if (i3 == e) acc += dfeat[(int64_t)(r + 3) * 64 + 31 + col];
+        }
+    }
+    for (; r < r1; ++r)
+        if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * 64 + 31 + col];
+    red[part][col] = acc;
     __syncthreads();
-    for (int r = threadIdx.x; r < n_rays; r += 256)
-        if (eidx[r] == e)   // a few dozen rays per row: LDS atomics are fine here
-            for (int c = 0; c < emb_dim; ++c) atomicAdd(&red[c], dfeat[(int64_t)r * 64 + 31 + c]);
-    __syncthreads();
-    if ((int)threadIdx.x < emb_dim) d_emb[(int64_t)e * emb_dim + threadIdx.x] += red[threadIdx.x];
+    if (part == 0 && col < emb_dim) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += red[p][col];
+        atomicAdd(&d_emb[(int64_t)e * emb_dim + col], s);
+    }
 }
 
 }  // namespace
@@ -345,7 +365,7 @@ extern "C" int lse_ray_features_bwd(const float *rays_d, const float *d_feat, co
         hipLaunchKernelGGL(ray_features_bwd_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, lse::as_stream(stream),
                            rays_d, d_feat, emb_idx, n_rays, emb_dim, d_rays_d, d_emb_table);
     if (d_emb_table && emb_idx && emb_dim > 0)
-        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows), dim3(256), 0, lse::as_stream(stream), d_feat, emb_idx, n_rays,
+        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows, 8), dim3(256), 0, lse::as_stream(stream), d_feat, emb_idx, n_rays,
                            emb_dim, d_emb_table);
     return lse::check_launch("lse_ray_features_bwd");
 }

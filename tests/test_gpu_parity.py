@@ -451,18 +451,18 @@ def test_mlp_fused_density_head_and_compact_output():
     sel = torch.rand(N, generator=g) < 0.8
     pc, xc = params.clone().requires_grad_(True), x.clone().requires_grad_(True)
     h_ref = om.forward(xc, pc)
-    h_ref_big = h_ref * torch.tensor([40.0] + [1.0] * 15)          # push some logits beyond the +-15 clamp of trunc_exp
+    h_ref_big = h_ref * torch.tensor([12.0] + [1.0] * 15)          # push some logits beyond the +-15 clamp of trunc_exp
     sig_ref = 0.7 * trunc_exp(h_ref_big[:, 0]) * sel
     meta = ops.MlpMeta(32, 64, 1, _lib.LSE_ACT_NONE, _lib.LSE_IN_LEVELMAJOR)
-    scale_w = torch.cat([torch.ones(64 * 32), torch.cat([torch.full((64,), 40.0), torch.ones(15 * 64)])])
-    pg = (params * scale_w).clone().cuda().requires_grad_(True)      # same effect: row 0 of W_out scaled by 40
+    scale_w = torch.cat([torch.ones(64 * 32), torch.cat([torch.full((64,), 12.0), torch.ones(15 * 64)])])
+    pg = (params * scale_w).clone().cuda().requires_grad_(True)      # same effect: row 0 of W_out scaled by 12
     xin = x.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda().requires_grad_(True)
     h, sig = ops.fused_mlp(pg, xin, meta, N, density=(sel.cuda().to(torch.uint8), 0.7))
     assert nmax_err(h, h_ref_big) < TOL_FWD and nmax_err(sig, sig_ref, 1e-3) < 5 * TOL_FWD
     w1, w2 = torch.randn(N, 16, generator=g), torch.randn(N, generator=g) * 1e-3
     ((h_ref_big * w1).sum() + (sig_ref * w2).sum()).backward()
     ((h * w1.cuda()).sum() + (sig * w2.cuda()).sum()).backward()
-    assert nmax_err(pg.grad / scale_w.cuda(), pc.grad) < TOL_GRAD
+    assert nmax_err(pg.grad * scale_w.cuda(), pc.grad) < TOL_GRAD      # pg = scale_w * pc  =>  dL/dpc = scale_w * dL/dpg
     assert nmax_err(xin.grad.permute(1, 0, 2).reshape(N, 32), xc.grad) < TOL_GRAD
     # compact head output
     oh = TcnnMLP(16, 3, 64, 3, "Sigmoid")
