@@ -121,10 +121,12 @@ def main():
     from lsenerf_amd.optim import FlatAdam, FlatParams
     import torch.distributed as tdist
 
-    rank, world, local = ldist.init_from_env("nccl")
+    # RCCL ("nccl") over xGMI on a real multi-GPU node; LSE_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse
+    # the multi-rank control path on a single-GPU box (the collective then stages through the host).
+    rank, world, local = ldist.init_from_env(os.environ.get("LSE_BENCH_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _lib.load()
 
@@ -168,6 +170,12 @@ def main():
         dom_ms = kern_ms[dom] / max(launches[dom], 1)
         achieved = HASH_BYTES_PER_SAMPLE * n_samples / (dom_ms * 1e-3) / 1e9
         b_step = n_samples * BYTES_PER_SAMPLE_STEP + 8 * 4 * flat.numel
+        traffic = None
+        try:   # committed PMC summary of the same kernels (bench.py cannot run rocprofv3 on itself); see profiles/pmc_traffic.json
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(dom, {}).get("bytes")
+        except OSError:
+            pass
         line = {
             "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -178,7 +186,7 @@ def main():
                        "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": SAMPLES_PER_RAY, "samples_per_step": n_samples,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples},
             "step_roofline": {"algorithmic_bytes_per_step": b_step,
                               "achieved_GBps": b_step / (ms_per_step * 1e-3) / 1e9 * 1.0,
@@ -187,7 +195,7 @@ def main():
                      "achieved_TFLOPs": MLP_FLOP_PER_SAMPLE * n_samples / (1e-3 * (kern_ms.get("lse_mlp_fwd", 0) + kern_ms.get(
                          "lse_mlp_bwd", 0) + kern_ms.get("lse_mlp_wgrad", 0) + 1e-9)) / 1e12, "peak_TFLOPs": 157.3},
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
-            "loss": float(loss),
+            "loss": float(loss.detach()),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -141,63 +141,67 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
     }
 }
 
-// Backward.  Lane mapping: 16 lanes per sample -- lane k of a 16-lane group owns (corner k>>1, feature k&1) -- and each
-// group walks 16 CONSECUTIVE samples of the ray (one per round).  Consequences:
+// Backward.  Lane mapping: 16 lanes per sample -- lane k of a 16-lane group owns (corner k>>1, feature k&1) -- and a
+// wave owns 64 consecutive samples of the packed (ray-sorted) stream, processed in 16 rounds of 4 samples.
 //   * one atomic wave-instruction covers 4 samples x 8 corners x 2 features: the two features of an entry and the
-//     x / x+1 corner pair are neighbouring dwords, so the instruction touches ~18 64-byte lines instead of 64
-//     (memory-side float atomics are priced per line request, MI355X_MICROARCH.md "Global float atomics");
-//   * consecutive samples of a ray stay in the same cell at the coarse and middle levels: each lane run-length
-//     accumulates (index, sum) in registers and only issues an atomic when its entry index changes;
-//   * d(x) partial products are kept per round in registers and reduced over the 16 lanes once, after all levels.
-template <bool WITH_DX>
+//     x / x+1 corner pair are neighbouring dwords, so the instruction touches far fewer 64-byte lines than lanes
+//     (memory-side float atomics are priced per line request, MI355X_MICROARCH.md "Global float atomics"; measured
+//     here: identical rate for agent / workgroup / wavefront scope, tools/micro/atomic_scope.hip);
+//   * every lane run-length accumulates (index, sum) in registers and only issues an atomic when its entry index
+//     changes between consecutive rounds;
+//   * which 4 samples share a round is chosen PER LEVEL (tools/sim_hash_bwd_requests.py models the request counts):
+//       blocked      group g walks samples 16g + r  -> long runs: best where consecutive samples share a cell (coarse/mid);
+//       interleaved  group g takes sample 4r + g     -> the instruction covers 4 CONSECUTIVE samples whose cells share
+//                    faces, i.e. lines: best at the fine levels (~25 % fewer line requests there);
+//   * positions are staged once per wave in LDS (either mapping reads them by sample id); d(x) is reduced over the 16
+//     lanes of a group and accumulated per sample in LDS by the group's first lane (plain read-add-write: within a
+//     round the 4 groups own 4 different samples, rounds are sequential).
+template <bool WITH_DX, int kRounds>
 __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float *__restrict__ x,
                                                        const float *__restrict__ dy,
                                                        const float *__restrict__ table, float *__restrict__ dtable,
-                                                       float *__restrict__ dx, int64_t n)
+                                                       float *__restrict__ dx, int64_t n, float interleave_from_scale)
 {
-    constexpr int kRounds = 16;
-    const int lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
+    constexpr int kChunk = 4 * kRounds;        // samples per wave
+    __shared__ float s_x[4][kChunk][3];
+    __shared__ float s_dx[4][kChunk][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
     const int corner = k >> 1, f = k & 1;
-    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    const int64_t sb = wave_base + grp * kRounds;     // first sample of this 16-lane group
+    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
     if (wave_base >= n) return;
-
-    float xs[kRounds][3];
-    bool valid[kRounds];
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int64_t i = sb + r;
-        valid[r] = i < n;
-        const int64_t ii = valid[r] ? i : n - 1;
-        xs[r][0] = x[ii * 3 + 0];
-        xs[r][1] = x[ii * 3 + 1];
-        xs[r][2] = x[ii * 3 + 2];
+    for (int c = lane; c < kChunk; c += 64) {
+        const int64_t i = wave_base + c;
+        const int64_t ii = i < n ? i : n - 1;
+        s_x[wave][c][0] = x[ii * 3 + 0];
+        s_x[wave][c][1] = x[ii * 3 + 1];
+        s_x[wave][c][2] = x[ii * 3 + 2];
+        if (WITH_DX) s_dx[wave][c][0] = s_dx[wave][c][1] = s_dx[wave][c][2] = 0.f;
     }
-    float dxp[kRounds][3];
-    if (WITH_DX) {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) dxp[r][0] = dxp[r][1] = dxp[r][2] = 0.f;
-    }
+    __builtin_amdgcn_wave_barrier();   // LDS slots are private to this wave; DS ops of a wave execute in order
     const uint32_t cx = corner & 1, cy = (corner >> 1) & 1, cz = (corner >> 2) & 1;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
 
     for (int l = 0; l < g.n_levels; ++l) {
         const LevelInfo li = level_info(g, l);
+        const bool interleaved = li.scale >= interleave_from_scale;
         float *__restrict__ dt = dtable + 2 * (size_t)li.offset + f;
         const float *__restrict__ tab = WITH_DX ? table + 2 * (size_t)li.offset + f : nullptr;
         const float *__restrict__ dyl = dy + 2 * (size_t)l * n + f;
         uint32_t cur = kNone;
         float acc = 0.f;
-#pragma unroll
+#pragma unroll 4
         for (int r = 0; r < kRounds; ++r) {
+            const int sl = interleaved ? (4 * r + grp) : (kRounds * grp + r);   // sample slot within the wave's 64
+            const bool valid = wave_base + sl < n;
             float w0, w1, w2;
             uint32_t p0, p1, p2;
-            pos_fract(xs[r][0], li.scale, w0, p0);
-            pos_fract(xs[r][1], li.scale, w1, p1);
-            pos_fract(xs[r][2], li.scale, w2, p2);
-            const uint32_t idx = valid[r] ? grid_index(li, p0 + cx, p1 + cy, p2 + cz) : kNone;
+            pos_fract(s_x[wave][sl][0], li.scale, w0, p0);
+            pos_fract(s_x[wave][sl][1], li.scale, w1, p1);
+            pos_fract(s_x[wave][sl][2], li.scale, w2, p2);
+            const uint32_t idx = valid ? grid_index(li, p0 + cx, p1 + cy, p2 + cz) : kNone;
             const float sx = cx ? w0 : 1.f - w0, sy = cy ? w1 : 1.f - w1, sz = cz ? w2 : 1.f - w2;
-            const int64_t ii = valid[r] ? sb + r : n - 1;
+            const int64_t ii = valid ? wave_base + sl : n - 1;
             const float gy = dyl[2 * ii];
             const float v = sx * sy * sz * gy;
             if (idx == cur) {
@@ -208,31 +212,35 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
                 acc = v;
             }
             if (WITH_DX) {
-                const float tv = valid[r] ? tab[2 * (size_t)idx] : 0.f;
+                const float tv = valid ? tab[2 * (size_t)idx] : 0.f;
                 const float t = li.scale * gy * tv;
-                dxp[r][0] = fmaf(t * (cx ? 1.f : -1.f), sy * sz, dxp[r][0]);
-                dxp[r][1] = fmaf(t * (cy ? 1.f : -1.f), sx * sz, dxp[r][1]);
-                dxp[r][2] = fmaf(t * (cz ? 1.f : -1.f), sx * sy, dxp[r][2]);
+                float d0 = t * (cx ? 1.f : -1.f) * (sy * sz);
+                float d1 = t * (cy ? 1.f : -1.f) * (sx * sz);
+                float d2 = t * (cz ? 1.f : -1.f) * (sx * sy);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    d0 += __shfl_xor(d0, o, 64);
+                    d1 += __shfl_xor(d1, o, 64);
+                    d2 += __shfl_xor(d2, o, 64);
+                }
+                if (k == 0) {
+                    s_dx[wave][sl][0] += d0;
+                    s_dx[wave][sl][1] += d1;
+                    s_dx[wave][sl][2] += d2;
+                }
             }
         }
         if (cur != kNone) atomicAdd(dt + 2 * (size_t)cur, acc);
     }
     if (WITH_DX) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float v = dxp[r][d];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                dxp[r][d] = v;
-            }
-            if (k == 0 && valid[r]) {
-                dx[(sb + r) * 3 + 0] = dxp[r][0];
-                dx[(sb + r) * 3 + 1] = dxp[r][1];
-                dx[(sb + r) * 3 + 2] = dxp[r][2];
+        for (int c = lane; c < kChunk; c += 64) {
+            const int64_t i = wave_base + c;
+            if (i < n) {
+                dx[i * 3 + 0] = s_dx[wave][c][0];
+                dx[i * 3 + 1] = s_dx[wave][c][1];
+                dx[i * 3 + 2] = s_dx[wave][c][2];
             }
         }
     }
@@ -285,13 +293,24 @@ extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const f
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(x01 && dy && dtable, "lse_hash_bwd: null pointer");
     LSE_REQUIRE(!dx || table, "lse_hash_bwd: dx requested but table is null");
-    const int64_t blocks = (n + 255) / 256;
-    LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
-    if (dx)
-        hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01, dy,
-                           table, dtable, dx, n);
-    else
-        hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, lse::as_stream(stream), g, x01, dy,
-                           (const float *)nullptr, dtable, dx, n);
+    // Levels with scale >= il_scale use the interleaved (4 consecutive samples per instruction) mapping.  Measured
+    // negative on MI355X (same-address lanes inside one atomic instruction serialise): default = never.
+    static const float il_scale = getenv("LSE_HASH_BWD_INTERLEAVE_SCALE") ? (float)atof(getenv("LSE_HASH_BWD_INTERLEAVE_SCALE")) : 1e30f;
+    static const int rounds = getenv("LSE_HASH_BWD_ROUNDS") ? atoi(getenv("LSE_HASH_BWD_ROUNDS")) : 32;
+    hipStream_t st = lse::as_stream(stream);
+    const float *tb = dx ? table : nullptr;
+#define LSE_LAUNCH_BWD(R)                                                                                             \
+    do {                                                                                                              \
+        const int64_t blocks = (n + 4 * 4 * R - 1) / (4 * 4 * R);                                                     \
+        LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");                                            \
+        if (dx) hipLaunchKernelGGL((hash_bwd_kernel<true, R>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy, tb, \
+                                   dtable, dx, n, il_scale);                                                          \
+        else hipLaunchKernelGGL((hash_bwd_kernel<false, R>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy, tb,   \
+                                dtable, dx, n, il_scale);                                                             \
+    } while (0)
+    if (rounds == 32) LSE_LAUNCH_BWD(32);
+    else if (rounds == 64) LSE_LAUNCH_BWD(64);
+    else LSE_LAUNCH_BWD(16);
+#undef LSE_LAUNCH_BWD
     return lse::check_launch("lse_hash_bwd");
 }

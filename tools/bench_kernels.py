@@ -51,6 +51,17 @@ def main():
         print(f"hash_bwd(dx) median {med:.3f} ms  min {mn:.3f} ms  -> {1024*N/med/1e6:.0f} GB/s algorithmic", flush=True)
         med, mn = timeit(lambda: bwd(False))
         print(f"hash_bwd(no dx) median {med:.3f} ms  min {mn:.3f}", flush=True)
+    if want("mlp"):
+        from lsenerf_amd import _lib as L
+        for name, meta, xin in (("head", ops.MlpMeta(16, 64, 2, L.LSE_ACT_SIGMOID, L.LSE_IN_ROWMAJOR), torch.randn(N, 16, device=dev)),
+                                ("base", ops.MlpMeta(32, 64, 1, L.LSE_ACT_NONE, L.LSE_IN_LEVELMAJOR), y)):
+            p = torch.randn(meta.n_params, device=dev) * 0.1
+            with torch.no_grad():
+                med, mn = timeit(lambda: ops.fused_mlp(p, xin, meta, N, out_cols=4 if name == "head" else 16))
+            print(f"mlp_fwd {name} (no act save) median {med:.3f} ms", flush=True)
+            pg = p.clone().requires_grad_(True)
+            med, mn = timeit(lambda: ops.fused_mlp(pg, xin, meta, N, out_cols=4 if name == "head" else 16))
+            print(f"mlp_fwd {name} (act saved)   median {med:.3f} ms", flush=True)
     if want("traverse"):
         from lsenerf_amd import LSEOccGridEstimator
         est = LSEOccGridEstimator([-1, -1, -1, 1, 1, 1], 128, 4).to(dev); est.mark_all_occupied()

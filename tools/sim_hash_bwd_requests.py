@@ -1,0 +1,56 @@
+"""CPU model of hash_bwd atomic line requests (64-B lines) per sample for different lane<->sample mappings."""
+import numpy as np, sys
+sys.path.insert(0, '.')
+import torch
+from oracle import hashgrid as hg
+from oracle.field import contract_inf
+meta = hg.tcnn_grid_meta()
+R, S = 48, 1024
+g = torch.Generator().manual_seed(1)
+o = torch.rand(R, 3, generator=g) - 0.5
+d = torch.randn(R, 3, generator=g); d = d / d.norm(dim=-1, keepdim=True)
+step = 2 * 3 ** 0.5 / 1000
+t = 0.05 + step * (torch.arange(S) + 0.5)
+pos = o[:, None, :] + d[:, None, :] * t[None, :, None]
+x01 = ((contract_inf(pos.reshape(-1, 3)) + 2) / 4).float()
+N = x01.shape[0]
+tot = {"blocked": 0, "interleaved": 0, "hybrid": 0, "lanes": 0}
+per_level = []
+for l in range(16):
+    idx = hg.tcnn_corner_indices(x01, meta, l).numpy()          # [N,8] absolute entry index
+    line = idx >> 3
+    res = {}
+    for name in ("blocked", "interleaved"):
+        req = 0; lanes = 0
+        for w in range(N // 64):
+            base = w * 64
+            # sample handled by group gi at round r
+            if name == "blocked":
+                samp = np.array([[16 * gi + r for gi in range(4)] for r in range(16)]) + base
+            else:
+                samp = np.array([[4 * r + gi for gi in range(4)] for r in range(16)]) + base
+            cur = np.full((4, 8), -1, dtype=np.int64)
+            for r in range(16):
+                new = idx[samp[r]]                                 # [4,8]
+                flush = (cur != new) & (cur >= 0)
+                if flush.any():
+                    req += len(np.unique(cur[flush] >> 3)); lanes += int(flush.sum())
+                cur = new
+            req += len(np.unique(cur >> 3)); lanes += 32
+        res[name] = req / N
+        if name == "blocked": tot["lanes"] += lanes / N
+    per_level.append(res)
+    tot["blocked"] += res["blocked"]; tot["interleaved"] += res["interleaved"]; tot["hybrid"] += min(res.values())
+    print(f"level {l:2d} res {meta.resolutions[l]:5d}: requests/sample blocked {res['blocked']:.3f}  interleaved {res['interleaved']:.3f}")
+print("total requests/sample:", {k: round(v, 2) for k, v in tot.items()})
+print("predicted atomic time at 20.7 G req/s for N=4.19M: blocked %.2f ms, hybrid %.2f ms" % (tot["blocked"] * 4194304 / 20.7e9 * 1e3, tot["hybrid"] * 4194304 / 20.7e9 * 1e3))
+
+# lower bounds: every distinct line (or entry) requested once per chunk of C consecutive samples
+for C in (64, 256, 1024):
+    tl = te = 0.0
+    for l in range(16):
+        idx = hg.tcnn_corner_indices(x01, meta, l).numpy()
+        for w in range(N // C):
+            blk = idx[w * C:(w + 1) * C].reshape(-1)
+            tl += len(np.unique(blk >> 3)); te += len(np.unique(blk))
+    print(f"chunk {C:5d} samples: distinct lines/sample {tl / N:.2f}, distinct entries/sample {te / N:.2f}")
