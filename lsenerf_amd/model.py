@@ -302,6 +302,10 @@ class LSENeRFModel(nn.Module):
     # -- R:lse_nerf/lsenerf.py:329-377 ----------------------------------------------------------------
     def get_outputs(self, ray_bundle: RayBundle, ev_out=False, jitter: Optional[Tensor] = None, **kwargs):
         out_dict = self.exec_get_outputs(ray_bundle, jitter=jitter)
+        return self.route_outputs(out_dict, ray_bundle, ev_out=ev_out, **kwargs)
+
+    def route_outputs(self, out_dict: Dict[str, Tensor], ray_bundle: RayBundle, ev_out=False, **kwargs):
+        """The mapper routing of R:lse_nerf/lsenerf.py:333-377, applied to the hot path's outputs."""
         cfg = self.config
         clamp_out = torch.clamp(out_dict["rgb"], 1e-5)
         if cfg.use_mapping or cfg.map_mode == "rgb_evs":
