@@ -163,8 +163,12 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
                                                        float *__restrict__ dx, int64_t n, float interleave_from_scale)
 {
     constexpr int kChunk = 4 * kRounds;        // samples per wave
-    __shared__ float s_x[4][kChunk][3];
-    __shared__ float s_dx[4][kChunk][3];
+    // SoA + one pad word per 16-lane group: the 4 groups of a wave touch slots kRounds apart, which would otherwise fall
+    // into the same LDS bank (4-way conflict on every position read and every d(x) update)
+    constexpr int kPitch = kChunk + 4;
+    __shared__ float s_x[4][3][kPitch];
+    __shared__ float s_dx[4][3][kPitch];
+#define LSE_SLOT(sl) ((sl) + (sl) / kRounds)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
     const int corner = k >> 1, f = k & 1;
     const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
     for (int c = lane; c < kChunk; c += 64) {
         const int64_t i = wave_base + c;
         const int64_t ii = i < n ? i : n - 1;
-        s_x[wave][c][0] = x[ii * 3 + 0];
-        s_x[wave][c][1] = x[ii * 3 + 1];
-        s_x[wave][c][2] = x[ii * 3 + 2];
-        if (WITH_DX) s_dx[wave][c][0] = s_dx[wave][c][1] = s_dx[wave][c][2] = 0.f;
+        s_x[wave][0][LSE_SLOT(c)] = x[ii * 3 + 0];
+        s_x[wave][1][LSE_SLOT(c)] = x[ii * 3 + 1];
+        s_x[wave][2][LSE_SLOT(c)] = x[ii * 3 + 2];
+        if (WITH_DX) s_dx[wave][0][LSE_SLOT(c)] = s_dx[wave][1][LSE_SLOT(c)] = s_dx[wave][2][LSE_SLOT(c)] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();   // LDS slots are private to this wave; DS ops of a wave execute in order
     const uint32_t cx = corner & 1, cy = (corner >> 1) & 1, cz = (corner >> 2) & 1;
@@ -196,9 +200,10 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
             const bool valid = wave_base + sl < n;
             float w0, w1, w2;
             uint32_t p0, p1, p2;
-            pos_fract(s_x[wave][sl][0], li.scale, w0, p0);
-            pos_fract(s_x[wave][sl][1], li.scale, w1, p1);
-            pos_fract(s_x[wave][sl][2], li.scale, w2, p2);
+            const int slot = LSE_SLOT(sl);
+            pos_fract(s_x[wave][0][slot], li.scale, w0, p0);
+            pos_fract(s_x[wave][1][slot], li.scale, w1, p1);
+            pos_fract(s_x[wave][2][slot], li.scale, w2, p2);
             const uint32_t idx = valid ? grid_index(li, p0 + cx, p1 + cy, p2 + cz) : kNone;
             const float sx = cx ? w0 : 1.f - w0, sy = cy ? w1 : 1.f - w1, sz = cz ? w2 : 1.f - w2;
             const int64_t ii = valid ? wave_base + sl : n - 1;
@@ -224,9 +229,9 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
                     d2 += __shfl_xor(d2, o, 64);
                 }
                 if (k == 0) {
-                    s_dx[wave][sl][0] += d0;
-                    s_dx[wave][sl][1] += d1;
-                    s_dx[wave][sl][2] += d2;
+                    s_dx[wave][0][slot] += d0;
+                    s_dx[wave][1][slot] += d1;
+                    s_dx[wave][2][slot] += d2;
                 }
             }
         }
@@ -238,12 +243,13 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
         for (int c = lane; c < kChunk; c += 64) {
             const int64_t i = wave_base + c;
             if (i < n) {
-                dx[i * 3 + 0] = s_dx[wave][c][0];
-                dx[i * 3 + 1] = s_dx[wave][c][1];
-                dx[i * 3 + 2] = s_dx[wave][c][2];
+                dx[i * 3 + 0] = s_dx[wave][0][LSE_SLOT(c)];
+                dx[i * 3 + 1] = s_dx[wave][1][LSE_SLOT(c)];
+                dx[i * 3 + 2] = s_dx[wave][2][LSE_SLOT(c)];
             }
         }
     }
+#undef LSE_SLOT
 }
 
 int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)

@@ -1,0 +1,133 @@
+"""GPU tests of the reference-interface surface beyond the training fast path: eval mode, empty rays, the generic
+RaySamples API of LSEField (what a nerfstudio caller would use), renderer modules, occupancy refresh callback."""
+import pytest
+import torch
+
+from tests.util import TOL_FWD, TOL_GRAD, make_model_pair, nmax_err, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _bundle(o, d, **kw):
+    from lsenerf_amd import RayBundle
+    return RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(o.shape[0], 1, dtype=torch.long).cuda(), **kw)
+
+
+@pytest.mark.parametrize("linear", [False, True])
+def test_eval_mode_forward_matches_oracle(linear):
+    """not training: no sigma_fn pre-pass, no stratified jitter (R: VolumetricSampler), zero-embedding eval mode
+    (R:lse_nerf/lse_embeddings.py:51-55), eval clamp of RGBRenderer unless LinearRenderer (R:lse_nerf/lse_renderer.py)."""
+    hip, orc = make_model_pair(grid_levels=2, grid_resolution=32, occupied_frac=0.5, param_scale=300.0, emb_type="evs_emb")
+    if linear:
+        from lsenerf_amd import LinearRenderer
+        hip.renderer_rgb = LinearRenderer(background_color="random")
+        orc.linear_renderer = True
+    with torch.no_grad():   # push colours above 1 so the clamp matters
+        hip.field.mlp_head.params[-16 * 64:].mul_(0.0)
+        hip.field.mlp_base_mlp.params[-16 * 64:-15 * 64].add_(0.3)
+    from tests.util import sync_params_to_oracle
+    sync_params_to_oracle(hip, orc.field)
+    hip.eval(); orc.training = False; orc.field.training = False
+    o, d = random_rays(80, seed=5)
+    with torch.no_grad():
+        out = hip.exec_get_outputs(_bundle(o, d, metadata={"appearance_id": torch.zeros(80, dtype=torch.long).cuda()}))
+        ref = orc.exec_get_outputs(o, d, torch.zeros(80, dtype=torch.long))
+    assert torch.equal(out["num_samples_per_ray"].cpu(), ref["num_samples_per_ray"])       # sampler: bit-exact counts
+    for k in ("rgb", "accumulation", "depth"):
+        assert nmax_err(out[k], ref[k], 1e-3) < 5 * TOL_FWD, k
+    final = hip.route_outputs(out, None)
+    assert float(final["rgb"].max()) <= 1.0 and float(final["rgb"].min()) >= 0.0              # R:lse_nerf/lsenerf.py:372-373
+
+
+def test_rays_without_samples_take_the_fake_sample_path():
+    """All rays miss every grid -> VolumetricSampler inserts one fake sample (ray 0, t = 1); outputs stay finite."""
+    hip, orc = make_model_pair(grid_levels=1, grid_resolution=16, occupied_frac=0.5, param_scale=300.0)
+    hip.train(); orc.training = True
+    o = torch.tensor([[5.0, 5.0, 5.0], [6.0, 5.0, 5.0], [7.0, 5.0, 5.0]])
+    d = torch.tensor([[1.0, 0, 0]] * 3)
+    out = hip.exec_get_outputs(_bundle(o, d), jitter=torch.zeros(3).cuda())
+    ref = orc.exec_get_outputs(o, d, None, jitter=torch.zeros(3))
+    assert out["num_samples_per_ray"].tolist() == ref["num_samples_per_ray"].tolist() == [1, 0, 0]
+    assert nmax_err(out["rgb"], ref["rgb"], 1e-3) < 5 * TOL_FWD and bool(torch.isfinite(out["depth"]).all())
+    out["rgb"].sum().backward()                                                              # backward through an (almost) empty batch
+    assert all(torch.isfinite(p.grad).all() for p in hip.field.parameters() if p.grad is not None)
+    # an occupancy grid with nothing in it: same path
+    hip.occupancy_grid.binaries.zero_(); orc.grid.binaries.zero_()
+    o2, d2 = random_rays(16, seed=1)
+    out2 = hip.exec_get_outputs(_bundle(o2, d2), jitter=torch.zeros(16).cuda())
+    assert int(out2["num_samples_per_ray"].sum()) == 1
+
+
+def test_generic_raysamples_api_of_lsefield():
+    """LSEField.get_density / get_outputs / forward / density_fn with plain per-sample tensors of any batch shape (no
+    packed bookkeeping) -- what a nerfstudio caller passes -- against the oracle field."""
+    from lsenerf_amd import Frustums, RaySamples
+    from lsenerf_amd.field import FieldHeadNames
+    hip, orc = make_model_pair(grid_levels=1, grid_resolution=16, param_scale=300.0, emb_type="evs_emb")
+    fld = hip.field
+    fld.train(); orc.field.training = True
+    g = torch.Generator().manual_seed(0)
+    B, S = 6, 11
+    o = (torch.rand(B, S, 3, generator=g) - 0.5) * 3
+    d = torch.nn.functional.normalize(torch.randn(B, S, 3, generator=g), dim=-1)
+    st = torch.rand(B, S, 1, generator=g)
+    en = st + 0.01
+    aid = torch.randint(0, 8, (B, S), generator=g)
+    rs = RaySamples(Frustums(o.cuda(), d.cuda(), st.cuda(), en.cuda()), camera_indices=torch.zeros(B, S, 1, dtype=torch.long).cuda(),
+                    metadata={"appearance_id": aid.cuda()})
+    outs = fld(rs)
+    dens, rgb = outs[FieldHeadNames.DENSITY], outs[FieldHeadNames.RGB]
+    assert dens.shape == (B, S, 1) and rgb.shape == (B, S, 3)
+    pos = (o + d * (st + en) / 2).reshape(-1, 3)
+    dref, geo = orc.field.get_density(pos)
+    rref = orc.field.get_outputs(d.reshape(-1, 3), geo, aid.reshape(-1))
+    assert nmax_err(dens.reshape(-1), dref.reshape(-1)) < TOL_FWD and nmax_err(rgb.reshape(-1, 3), rref) < TOL_FWD
+    dfn = fld.density_fn(pos.cuda().view(B, S, 3))
+    assert dfn.shape == (B, S, 1) and nmax_err(dfn.reshape(-1), dref.reshape(-1)) < TOL_FWD
+    (dens.sum() + rgb.sum()).backward()
+    (dref.sum() + rref.sum()).backward()
+    assert nmax_err(fld.mlp_base_grid.params.grad, orc.field.params["grid"].grad, 1e-12) < TOL_GRAD
+    assert nmax_err(fld.embedding_appearance.embedding.weight.grad, orc.field.params["embedding"].grad, 1e-12) < TOL_GRAD
+    # tcnn-style encoding output [N, L*F]
+    enc = fld.mlp_base_grid(torch.rand(50, 3, generator=g).cuda())
+    assert enc.shape == (50, 32)
+
+
+def test_renderer_modules_match_oracle():
+    from lsenerf_amd import AccumulationRenderer, DepthRenderer, Frustums, LinearRenderer, RaySamples, RGBRenderer
+    from oracle import volrend as ovr
+    g = torch.Generator().manual_seed(1)
+    cnt = torch.tensor([3, 0, 70, 1])
+    ri = torch.repeat_interleave(torch.arange(4), cnt)
+    N = int(cnt.sum())
+    w = torch.rand(N, 1, generator=g) * 0.05
+    rgb = torch.rand(N, 3, generator=g) * 40           # linear radiance far above 1
+    ts = torch.rand(N, 1, generator=g)
+    rs = RaySamples(Frustums(torch.zeros(N, 3).cuda(), torch.zeros(N, 3).cuda(), ts.cuda(), (ts + 0.01).cuda()))
+    for Renderer, training, bg in ((RGBRenderer, True, "random"), (RGBRenderer, False, "random"), (LinearRenderer, False, "random"),
+                                   (RGBRenderer, True, "white")):
+        r = Renderer(background_color=bg).cuda()
+        r.train(training)
+        got = r(rgb.cuda(), w.cuda(), ri.cuda(), 4)
+        eff = True if Renderer is LinearRenderer else training
+        assert nmax_err(got, ovr.render_rgb(rgb, w, ri, 4, eff, bg)) < TOL_FWD
+    assert nmax_err(AccumulationRenderer()(w.cuda(), ri.cuda(), 4), ovr.render_accumulation(w, ri, 4)) < TOL_FWD
+    assert nmax_err(DepthRenderer("expected")(w.cuda(), rs, ri.cuda(), 4),
+                    ovr.render_depth_expected(w, ts[:, 0], ts[:, 0] + 0.01, ri, 4)) < TOL_FWD
+
+
+def test_training_callback_refreshes_occupancy_grid():
+    hip, _ = make_model_pair(grid_levels=2, grid_resolution=16, param_scale=300.0)
+    hip.train()
+    hip.occupancy_grid.binaries.zero_(); hip.occupancy_grid.occs.zero_()
+    (cb,) = hip.get_training_callbacks()
+    cb(0)                                                 # step 0 < warmup: every cell evaluated with field.density_fn * step
+    occs = hip.occupancy_grid.occs
+    assert float(occs.min()) >= 0 and float(occs.max()) > 0
+    thre = min(float(occs.mean()), 0.01)
+    assert torch.equal(hip.occupancy_grid.binaries.flatten(), occs > thre)
+    before = occs.clone()
+    cb(3)                                                 # not a multiple of 16: no update
+    assert torch.equal(before, hip.occupancy_grid.occs)
+    cb(320)                                               # sampled-cells branch
+    assert bool(torch.isfinite(hip.occupancy_grid.occs).all())
