@@ -79,7 +79,7 @@ class LSEOccGridEstimator(nn.Module):
             far_planes.contiguous(), render_step_size, cone_angle)
 
         # skip invisible space
-        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None):
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None) and t_starts.shape[0] > 0:
             if self._occ_mean_host is None:
                 self._occ_mean_host = self.occs.mean().item()
             alpha_thre = min(alpha_thre, self._occ_mean_host)

@@ -161,6 +161,8 @@ def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early
     R = packed_info.shape[0]
     n = t_starts.shape[0]
     dev = t_starts.device
+    if n == 0:   # nothing to cull (every ray missed every grid)
+        return ray_indices, t_starts, t_ends, packed_info, torch.empty(0, dtype=torch.uint8, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
     new_cnts = torch.empty(R, dtype=torch.int64, device=dev)
     _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
