@@ -120,21 +120,23 @@ int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, c
                  float *dx, int64_t n, lse_stream_t stream);
 
 /* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
- * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations [n_hidden_layers][N][width].
+ * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
+ * [n_hidden_layers][N][width] (what lse_mlp_wgrad reads); act_tiled = 1 -> tile-major, an opaque workspace of
+ * n_hidden_layers * roundup(N,16) * width floats that only lse_mlp_bwd (same act_tiled) understands.
  * out is [N,16] (out_cols = 16) or the compact [N,4] holding outputs 0..3 (out_cols = 4, e.g. rgb).
  * sigma_out (nullable): fused density head sigma[N] = density_scale * exp(out[:,0]) * selector (trunc_exp,
  * R:lse_nerf/lse_field.py:286-287); selector nullable. */
 int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
-                const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, float *sigma_out,
-                const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream);
+                const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, int32_t act_tiled,
+                float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream);
 /* backward: d_out[N,out_cols] (w.r.t. the activated output) -> d_in (layout of desc->in_layout; nullable) and, when
  * d_params is given, the weight gradients of every layer accumulated into d_params (same layout as params) in the
  * same pass (`in` = the layer-0 input is then required).  d_sigma (nullable): gradient of the fused density head, folded
  * into the gradient of output 0 (trunc_exp backward: * density_scale * exp(clamp(out0,-15,15)) * selector).
  * Optional outputs: d_out_pre[N,16], d_act[n_hidden_layers][N][width] (pre-activation gradients of every layer, what
  * lse_mlp_wgrad consumes), d_act0[N][width] (layer 0 only: the row_bias gradient before the per-ray sum). */
-int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, const float *out,
-                int32_t out_cols, const float *d_out, const float *d_sigma, const uint8_t *selector, float density_scale,
+int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, int32_t act_tiled,
+                const float *out, int32_t out_cols, const float *d_out, const float *d_sigma, const uint8_t *selector, float density_scale,
                 float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params, int64_t n,
                 lse_stream_t stream);
 /* unfused weight gradients from materialised d_act / d_out_pre, accumulate into d_params (same layout as params). */

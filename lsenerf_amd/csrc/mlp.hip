@@ -56,11 +56,22 @@ struct MlpArgs {
     float density_scale;
     const float *d_sigma;        // bwd, nullable: adds d_sigma * d(sigma)/d(out[:,0]) to the output gradient
     int out_cols;                // 16 (padded row) or 4 (compact: only outputs 0..3 are stored / have gradients)
+    int act_tiled;               // saved-activation layout: 0 = row-major [N][W], 1 = tile-major (see act_offset)
+    int64_t act_layer_stride;    // floats between the activation arrays of consecutive hidden layers
 };
 
 // CT = column tiles (of 16 samples) per wave iteration, NW = waves per workgroup (template parameters below).
 // (CT=4,NW=4): 64-sample tiles, fewest LDS weight reads per MFMA.  (CT=2,NW=8): half the registers -> 4 waves/SIMD,
 // which hides the first-touch HBM latency of the activation loads (the kernels are latency-, not MFMA-issue-bound).
+
+// Saved activations.  Row-major [N][W] is what the unfused lse_mlp_wgrad reads.  Tile-major stores every 16-sample x
+// 16-neuron block exactly in accumulator lane order ([N/16][W/16][64 lanes][4]): one store / load wave-instruction
+// moves 1 KiB contiguous instead of 16 pieces of 64 B at a 256-B stride (the forward's stores were issue-bound).
+template <int WIDTH>
+__device__ __forceinline__ int64_t act_offset(bool tiled, int64_t s, int rb, int q)
+{
+    return tiled ? ((((s >> 4) * (WIDTH / 16) + rb) * 64 + (q * 16 + (int)(s & 15))) << 2) : s * WIDTH + 16 * rb + 4 * q;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // forward
@@ -95,17 +106,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
     const int64_t n = a.n;
     constexpr int TS = 16 * CT;   // samples per wave tile
     const int64_t n_tiles = (n + TS - 1) / TS;
-    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
-        int64_t s[CT];
-        bool valid[CT];
+    const int64_t tile_stride = (int64_t)gridDim.x * NW;
+
+    // Inputs of a tile: layer-0 B operands breg[ct][ks] = in[sample][kidx_in(ks, q)] and the per-row layer-0 bias.
+    // They are fetched ONE TILE AHEAD: every wave of the chip walks its tiles in lockstep, so without the prefetch each
+    // tile's input loads queue behind a chip-wide burst of activation stores and compute + store time simply add up
+    // (measured: head 0.52 + 0.39 ms, base 0.29 + 0.27 ms).  Issued before the current tile's stores, the loads return
+    // early and the stores drain under the next tile's MFMAs.
+    auto load_inputs = [&](int64_t tile, int64_t (&s)[CT], bool (&valid)[CT], float (&breg)[CT][KS0], f32x4 (&bias)[HB][CT]) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int64_t si = tile * TS + ct * 16 + j;
             valid[ct] = si < n;
             s[ct] = valid[ct] ? si : n - 1;
         }
-        // ---- layer-0 B operands: breg[ct][ks] = in[sample][kidx_in(ks, q)]
-        float breg[CT][KS0];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             if (INL == LSE_IN_LEVELMAJOR) {
@@ -124,22 +138,44 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
                 }
             }
         }
-        // ---- layer 0
-        f32x4 h[HB][CT];
         if (a.row_bias) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[s[ct]] : s[ct];
 #pragma unroll
                 for (int rb = 0; rb < HB; ++rb)
-                    h[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
+                    bias[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
             }
         } else {
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) h[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct) bias[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+
+    int64_t s_nx[CT];
+    bool valid_nx[CT];
+    float breg_nx[CT][KS0];
+    f32x4 bias_nx[HB][CT];
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    if (tile < n_tiles) load_inputs(tile, s_nx, valid_nx, breg_nx, bias_nx);
+    for (; tile < n_tiles; tile += tile_stride) {
+        int64_t s[CT];
+        bool valid[CT];
+        float breg[CT][KS0];
+        f32x4 h[HB][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            s[ct] = s_nx[ct];
+            valid[ct] = valid_nx[ct];
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) breg[ct][ks] = breg_nx[ct][ks];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) h[rb][ct] = bias_nx[rb][ct];
+        }
+        if (tile + tile_stride < n_tiles) load_inputs(tile + tile_stride, s_nx, valid_nx, breg_nx, bias_nx);
+        // ---- layer 0
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) {
 #pragma unroll
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h[rb][ct][r], 0.f);
                 if (a.act && valid[ct])
-                    *reinterpret_cast<f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q) = h[rb][ct];
+                    *reinterpret_cast<f32x4 *>(a.act + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q)) = h[rb][ct];
             }
         // ---- hidden layer (width x width)
         if (NHL == 2) {
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
                         for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
                     }
                 }
-            float *act1 = a.act ? a.act + n * WIDTH : nullptr;
+            float *act1 = a.act ? a.act + a.act_layer_stride : nullptr;
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
@@ -185,7 +221,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h[rb][ct][r] = fmaxf(h2[rb][ct][r], 0.f);
                     if (act1 && valid[ct])
-                        *reinterpret_cast<f32x4 *>(act1 + s[ct] * WIDTH + 16 * rb + 4 * q) = h[rb][ct];
+                        *reinterpret_cast<f32x4 *>(act1 + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q)) = h[rb][ct];
                 }
         }
         // ---- output layer (16 x width)
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     const int64_t n = a.n;
     constexpr int TS = 16 * CT;   // samples per wave tile
     const int64_t n_tiles = (n + TS - 1) / TS;
-    const float *act_last = a.act + (int64_t)(NHL - 1) * n * WIDTH;
+    const float *act_last = a.act + (int64_t)(NHL - 1) * a.act_layer_stride;
     float *dact_last = a.d_act ? a.d_act + (int64_t)(NHL - 1) * n * WIDTH : nullptr;
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         const int64_t tile_base = tile * TS;
@@ -418,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
         for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(act_last + s[ct] * WIDTH + 16 * rb + 4 * q);
+                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(act_last + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
         // ---- output-layer weights: dWo[16 x WIDTH] += g^T * act_last
         if (WGRAD) wgrad_from_regs<1, HB, CT>(accO, tr, g, hv, j, q);
         // ---- dH_last
@@ -452,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    hv[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + s[ct] * WIDTH + 16 * rb + 4 * q);
+                    hv[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
             if constexpr (WGRAD && NHL == 2) wgrad_from_regs<HB, HB, CT>(acc1, tr, dh, hv, j, q);
             f32x4 d0[HB][CT];
 #pragma unroll
@@ -796,8 +832,8 @@ int gemm_tn_dispatch(const float *g, int m, const float *a, int k, int al, int64
 }  // namespace
 
 extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
-                           const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, float *sigma_out,
-                           const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream)
+                           const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, int32_t act_tiled,
+                           float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_fwd");
     if (rc) return rc;
@@ -809,12 +845,14 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     a.params = params; a.in = in; a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.out = out; a.act = act;
     a.n = n; a.out_activation = desc->out_activation; a.out_cols = out_cols; a.sigma_out = sigma_out;
     a.selector = selector; a.density_scale = density_scale;
+    a.act_tiled = act_tiled;
+    a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_fwd, desc, a, st);
 }
 
 extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act,
-                           const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
+                           int32_t act_tiled, const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
                            const uint8_t *selector, float density_scale, float *d_out_pre, float *d_act, float *d_act0,
                            float *d_in, float *d_params, int64_t n, lse_stream_t stream)
 {
@@ -833,6 +871,8 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_act0 = d_act0; a.d_in = d_in; a.d_params = d_params; a.n = n;
     a.out_activation = desc->out_activation; a.out_cols = out_cols; a.d_sigma = d_sigma; a.selector = selector;
     a.density_scale = density_scale;
+    a.act_tiled = act_tiled;
+    a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
 }

@@ -278,11 +278,14 @@ class _MlpFn(torch.autograd.Function):
         out = torch.empty((n, out_cols), dtype=torch.float32, device=dev)
         sigma = torch.empty(n, dtype=torch.float32, device=dev) if density_scale is not None else None
         need_grad = any(t is not None and t.requires_grad for t in (params, x, row_bias))
-        act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev) if need_grad else None
+        tiled = 1 if (FUSED_WGRAD and ACT_TILED) else 0
+        n_act = (n + 15) // 16 * 16 if tiled else n
+        act = torch.empty((meta.n_hidden_layers, n_act, meta.width), dtype=torch.float32, device=dev) if need_grad else None
+        ctx.act_tiled = tiled
         desc = meta.desc()
         _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
                   _f32(row_bias, "row_bias", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True),
-                  ctypes.c_void_p(out.data_ptr()), out_cols, _f32(act, "act", True), _f32(sigma, "sigma", True),
+                  ctypes.c_void_p(out.data_ptr()), out_cols, _f32(act, "act", True), tiled, _f32(sigma, "sigma", True),
                   _chk(selector, torch.uint8, "selector", True), float(density_scale or 0.0), n, _stream())
         ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info, selector)
         ctx.meta, ctx.n, ctx.out_cols, ctx.density_scale = meta, n, out_cols, density_scale
@@ -302,9 +305,9 @@ class _MlpFn(torch.autograd.Function):
         desc = meta.desc()
         scale = float(ctx.density_scale or 0.0)
         sel = _chk(selector, torch.uint8, "selector", True)
-        if FUSED_WGRAD or d_params is None:
+        if ctx.act_tiled or FUSED_WGRAD or d_params is None:
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
-                      _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
+                      ctx.act_tiled, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
                       _f32(d_params, "d_params", True), n, _stream())
         else:   # reference structure: materialise d_act, then one G^T A reduction per layer (padded outputs only)
@@ -312,7 +315,7 @@ class _MlpFn(torch.autograd.Function):
             d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
             d_act = torch.empty((meta.n_hidden_layers, n, meta.width), dtype=torch.float32, device=dev)
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
-                      _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
+                      0, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()), None,
                       _f32(d_in, "d_in", True), None, n, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
@@ -334,6 +337,7 @@ class _MlpFn(torch.autograd.Function):
 
 
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
+ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store/load instruction); fused path only
 
 
 def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None,

@@ -51,7 +51,7 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     from lsenerf_amd import _lib
     lib = _lib.load()
     d = _lib.MlpDesc(24, 64, 1, 0, 0)
-    rc = lib.lse_mlp_fwd(ctypes.byref(d), None, None, None, None, None, 16, None, None, None, 0.0, 8, None)
+    rc = lib.lse_mlp_fwd(ctypes.byref(d), None, None, None, None, None, 16, None, 0, None, None, 0.0, 8, None)
     assert rc == -1 and b"n_in" in lib.lse_last_error()
     g = _lib.GridDesc()
     g.n_levels, g.n_features = 16, 4
