@@ -134,11 +134,12 @@ int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, 
  * same pass (`in` = the layer-0 input is then required).  d_sigma (nullable): gradient of the fused density head, folded
  * into the gradient of output 0 (trunc_exp backward: * density_scale * exp(clamp(out0,-15,15)) * selector).
  * Optional outputs: d_out_pre[N,16], d_act[n_hidden_layers][N][width] (pre-activation gradients of every layer, what
- * lse_mlp_wgrad consumes), d_act0[N][width] (layer 0 only: the row_bias gradient before the per-ray sum). */
+ * lse_mlp_wgrad consumes), d_act0[N][width] (layer 0 only: the row_bias gradient before the per-row sum), or directly
+ * d_row_bias[rows][width] (accumulate; row_bias_idx[N] must be sorted, i.e. each row's samples contiguous). */
 int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, int32_t act_tiled,
                 const float *out, int32_t out_cols, const float *d_out, const float *d_sigma, const uint8_t *selector, float density_scale,
-                float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params, int64_t n,
-                lse_stream_t stream);
+                float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params,
+                const int32_t *row_bias_idx, float *d_row_bias, int64_t n, lse_stream_t stream);
 /* unfused weight gradients from materialised d_act / d_out_pre, accumulate into d_params (same layout as params). */
 int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
                   const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream);

@@ -44,7 +44,7 @@ SIGNATURES = {
     "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P],
     "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P],
     "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
-    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, I64, P],
+    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, I64, P],
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
     "lse_segment_sum_rows": [P, I32, P, I32, P, P],
     "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],

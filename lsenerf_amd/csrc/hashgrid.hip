@@ -160,7 +160,7 @@ template <bool WITH_DX, int kRounds>
 __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float *__restrict__ x,
                                                        const float *__restrict__ dy,
                                                        const float *__restrict__ table, float *__restrict__ dtable,
-                                                       float *__restrict__ dx, int64_t n, float interleave_from_scale)
+                                                       float *__restrict__ dx, int64_t n, float interleave_from_scale, int dbg)
 {
     constexpr int kChunk = 4 * kRounds;        // samples per wave
     // SoA + one pad word per 16-lane group: the 4 groups of a wave touch slots kRounds apart, which would otherwise fall
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
             if (idx == cur) {
                 acc += v;
             } else {
-                if (cur != kNone) atomicAdd(dt + 2 * (size_t)cur, acc);
+                if (cur != kNone && !(dbg & 1)) atomicAdd(dt + 2 * (size_t)cur, acc);
                 cur = idx;
                 acc = v;
             }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
                 }
             }
         }
-        if (cur != kNone) atomicAdd(dt + 2 * (size_t)cur, acc);
+        if (cur != kNone && !(dbg & 1)) atomicAdd(dt + 2 * (size_t)cur, acc);
     }
     if (WITH_DX) {
         __builtin_amdgcn_wave_barrier();
@@ -250,6 +250,287 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
         }
     }
 #undef LSE_SLOT
+}
+
+// Backward, line-cache variant (the default; LSE_HASH_BWD_IMPL=0 selects the kernel above, kept as the A/B reference).
+// The 16-lanes-per-sample kernel recomputes the position maths 16x and sends ~19 line requests per sample to the
+// memory-side atomic units (it is bound by them: 4.4 ms with, 1.2 ms without the atomics).  Here:
+//   * lane = sample (64 consecutive samples of the packed, ray-sorted stream): the position maths, the 8 indices and
+//     d(x) are computed once per sample, d(x) needs no cross-lane reduction at all;
+//   * consecutive lanes that sit in the same cell form a run; a flag-based segmented scan (DPP inside the 16-lane rows,
+//     early exit once no run is longer than the step, serial carry over the 3 row borders) leaves each run's 8 x 2
+//     corner sums in the run's last lane;
+//   * run ends add into a per-wave LDS cache of table LINES (key = entry index >> 3, payload 16 floats = one 64-B line
+//     of 8 entries x 2 features; 256 slots, one probe): 32-bit compare-and-swap claims the slot, a 64-bit
+//     compare-and-swap adds both features (ds_add_f32 runs at ~3 cycles per LANE on gfx950, tools/micro/lds_ops.hip);
+//     a corner whose slot belongs to another line goes straight to memory, so the cache is purely an optimisation;
+//   * after each level the occupied slots (kept in a list) are flushed with one 16-lane x 64-B atomic per line.
+//   Modelled requests per sample (tools/sim_hash_bwd_requests.py): 7.7 lines + 4.1 direct = 11.8 instead of 19
+//   (9.2 with a collision-free cache).  4.37 -> 3.54 ms; what remains is instruction issue (rocprof: VALU+SALU+LDS
+//   issue ~ 75 % of the SIMD cycles at the 2 waves/SIMD the 75 KB of LDS allow) plus ~2.4 ms of atomics underneath.
+//   Tried and dropped: more probe rounds (each costs more issue slots than its saved requests), two half-wave
+//   phases per fine level, ds_add_f32 payload adds, a slot function linear in the cell coordinates.
+constexpr uint32_t kNoLine = 0xFFFFFFFFu;
+
+// LDS pointers carry their address space so that every cache access is a ds_* instruction (generic pointers make the
+// compiler fold the LDS and the global fall-back path into flat atomics).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+
+// relaxed LDS compare-and-swap returning the previous value (no ordering fences: DS ops of a wave execute in order)
+__device__ __forceinline__ uint32_t lds_cas(lds_u32 *p, uint32_t expect, uint32_t desired)
+{
+    __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return expect;
+}
+__device__ __forceinline__ uint64_t lds_cas(lds_u64 *p, uint64_t expect, uint64_t desired)
+{
+    __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return expect;
+}
+
+__device__ __forceinline__ uint64_t add_pair(uint64_t bits, float a0, float a1)
+{
+    const float lo = __uint_as_float((uint32_t)bits) + a0, hi = __uint_as_float((uint32_t)(bits >> 32)) + a1;
+    return (uint64_t)__float_as_uint(lo) | ((uint64_t)__float_as_uint(hi) << 32);
+}
+
+// Row-local DPP shift: lane i receives the value of lane i-OFF of its 16-lane row, 0 if that lane is outside the row.
+template <int OFF>
+__device__ __forceinline__ float row_shr_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + OFF, 0xF, 0xF, true));
+}
+template <int OFF>
+__device__ __forceinline__ int row_shr_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true);
+}
+
+// One step of the flag-based segmented inclusive scan inside the 16-lane rows (pure VALU: DPP operand + fma).
+// Returns false (wave-uniform) when no lane needs this or any later step.
+template <int OFF>
+__device__ __forceinline__ bool seg_scan_row_step(float (&v)[16], int &flag, int row_pos)
+{
+    const bool need = !flag && row_pos >= OFF;
+    if (__builtin_amdgcn_ballot_w64(need) == 0) return false;
+    const float nf = need ? 1.f : 0.f;
+    const int fo = row_shr_i32<OFF>(flag);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = fmaf(row_shr_f32<OFF>(v[k]), nf, v[k]);
+    flag |= need ? fo : 0;
+    return true;
+}
+
+template <bool WITH_DX, int kSlots, int kRounds>
+__global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, const float *__restrict__ x,
+                                                              const float2 *__restrict__ dy,
+                                                              const float2 *__restrict__ table,
+                                                              float *__restrict__ dtable, float *__restrict__ dx,
+                                                              int64_t n, int dbg)
+{
+    static_assert(kRounds == 1, "one 64-sample round per wave");
+    constexpr int kChunk = 64 * kRounds;
+    __shared__ uint32_t s_key[4][kSlots];
+    __shared__ float s_val[4][kSlots * 16];
+    __shared__ uint32_t s_list[4][kSlots];      // (line << 8) | slot of every occupied slot
+    __shared__ uint32_t s_dummy32[4][64];
+    __shared__ uint64_t s_dummy64[4][64];
+    static_assert(kSlots <= 256, "slot id is packed into 8 bits");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
+    if (wave_base >= n) return;
+    lds_u32 *key = (lds_u32 *)&s_key[wave][0];
+    lds_f32 *val = (lds_f32 *)&s_val[wave][0];
+    lds_u32 *list = (lds_u32 *)&s_list[wave][0];
+    lds_u32 *dummy32 = (lds_u32 *)&s_dummy32[wave][lane];
+    lds_u64 *dummy64 = (lds_u64 *)&s_dummy64[wave][lane];
+    *dummy32 = kNoLine;
+    *dummy64 = 0;
+    for (int s = lane; s < kSlots; s += 64) key[s] = kNoLine;
+    for (int s = lane; s < kSlots * 16; s += 64) val[s] = 0.f;
+
+    float px[kRounds][3], dacc[kRounds][3];
+    int64_t si[kRounds];
+    bool valid[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int64_t i = wave_base + r * 64 + lane;
+        valid[r] = i < n;
+        si[r] = valid[r] ? i : n - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            px[r][d] = x[si[r] * 3 + d];
+            dacc[r][d] = 0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the cache is private to this wave; DS ops of a wave execute in order
+
+    for (int l = 0; l < g.n_levels; ++l) {
+        const LevelInfo li = level_info(g, l);
+        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;
+        const float2 *__restrict__ tab = table + li.offset;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            float w0, w1, w2;
+            uint32_t p0, p1, p2;
+            pos_fract(px[r][0], li.scale, w0, p0);
+            pos_fract(px[r][1], li.scale, w1, p1);
+            pos_fract(px[r][2], li.scale, w2, p2);
+            float2 gy = dy[(int64_t)l * n + si[r]];
+            if (!valid[r]) gy = make_float2(0.f, 0.f);
+            uint32_t idx[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) idx[c] = grid_index(li, p0 + (c & 1), p1 + ((c >> 1) & 1), p2 + ((c >> 2) & 1));
+            float2 tv[8];
+            if (WITH_DX) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
+            }
+            // runs of lanes in the same cell
+            const uint32_t q0 = __shfl_up(p0, 1), q1 = __shfl_up(p1, 1), q2 = __shfl_up(p2, 1);
+            const int head = (lane == 0) || (q0 != p0) || (q1 != p1) || (q2 != p2);
+            const int next_head = __shfl_down(head, 1);
+            const bool run_end = (lane == 63) || next_head;
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
+                v[2 * c] = wt * gy.x;
+                v[2 * c + 1] = wt * gy.y;
+            }
+            if (!(dbg & 4)) {
+                // segmented inclusive scan: inside the 16-lane rows with DPP, then a serial carry across the 3 row borders
+                const int row_pos = lane & 15;
+                int flag = head | (row_pos == 0);   // "my partial sum already starts at my run's head (or my row's start)"
+                if (seg_scan_row_step<1>(v, flag, row_pos) && seg_scan_row_step<2>(v, flag, row_pos) &&
+                    seg_scan_row_step<4>(v, flag, row_pos))
+                    seg_scan_row_step<8>(v, flag, row_pos);
+                // `open` = no run head between my row's first lane and me (inclusive): my run continues from the row before
+                int open = !head;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const int o = (off == 1) ? row_shr_i32<1>(open) : (off == 2) ? row_shr_i32<2>(open)
+                                : (off == 4) ? row_shr_i32<4>(open) : row_shr_i32<8>(open);
+                    open &= (row_pos >= off) ? o : 1;
+                }
+#pragma unroll
+                for (int R = 1; R < 4; ++R) {
+                    const bool m = (lane >> 4) == R && open;
+                    if (__builtin_amdgcn_ballot_w64(m) != 0) {
+                        const float mf = m ? 1.f : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            v[k] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 16 * R - 1)), mf, v[k]);
+                    }
+                }
+            }
+            if (WITH_DX) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float sx = (c & 1) ? w0 : 1.f - w0, sy = (c & 2) ? w1 : 1.f - w1, sz = (c & 4) ? w2 : 1.f - w2;
+                    const float t = li.scale * (gy.x * tv[c].x + gy.y * tv[c].y);
+                    dacc[r][0] += t * ((c & 1) ? 1.f : -1.f) * (sy * sz);
+                    dacc[r][1] += t * ((c & 2) ? 1.f : -1.f) * (sx * sz);
+                    dacc[r][2] += t * ((c & 4) ? 1.f : -1.f) * (sx * sy);
+                }
+            }
+            // ---- run ends add their 8 corner sums into the line cache, then the level's lines are flushed.
+            // The kernel is instruction-issue bound (rocprof: VALU+SALU+LDS issue ~ 3 ms of a 3.6 ms launch), so this part
+            // is written for few instructions: one probe per corner, no retry rounds (a lost slot goes straight to memory),
+            // every DS operation issued by all lanes (idle lanes aim at a private dummy word) so that a batch of 8 goes out
+            // back to back with one wait.
+            {
+                const bool act = run_end && !(dbg & 2);
+                uint32_t used = 0;   // occupied cache slots (wave-uniform)
+                if (__builtin_amdgcn_ballot_w64(act) != 0) {
+                    // multiplicative hash of the line id (a slot function linear in the cell coordinates was tried: more
+                    // collisions on ray-shaped line sets, tools/sim_hash_bwd_requests.py)
+                    uint32_t slot[8], old[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) slot[c] = (__umul24(idx[c] >> 3, 0x9E3779u) >> 16) & (kSlots - 1);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (idx[c] >> 3) : kNoLine);
+                    // float LDS atomics run at ~3 cycles per LANE on gfx950 (tools/micro/lds_ops.hip: ds_add_f32 194 cycles
+                    // per instruction, ds_cmpst_b64 22): add both features with one 64-bit compare-and-swap
+                    lds_u64 *va[8];
+                    bool to_mem[8];
+                    uint64_t cur[8], prev[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const bool claim = act && old[c] == kNoLine;
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                        if (cm) {
+                            if (claim)
+                                list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                    ((idx[c] >> 3) << 8) | slot[c];
+                            used += __builtin_popcountll(cm);
+                        }
+                        const bool ok = claim || (act && old[c] == (idx[c] >> 3));
+                        to_mem[c] = act && !ok;
+                        va[c] = ok ? (lds_u64 *)&val[slot[c] * 16 + (idx[c] & 7) * 2] : dummy64;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) cur[c] = *va[c];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) prev[c] = lds_cas(va[c], cur[c], add_pair(cur[c], v[2 * c], v[2 * c + 1]));
+                    bool retry = false;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) retry = retry || prev[c] != cur[c];
+                    if (__builtin_amdgcn_ballot_w64(retry) != 0) {   // rare: two lanes (or two corners of a lane) on one entry
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            while (prev[c] != cur[c]) {
+                                cur[c] = prev[c];
+                                prev[c] = lds_cas(va[c], cur[c], add_pair(cur[c], v[2 * c], v[2 * c + 1]));
+                            }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (to_mem[c]) {   // slot owned by another line: straight to memory
+                            atomicAdd(dt + 2 * (size_t)idx[c], v[2 * c]);
+                            atomicAdd(dt + 2 * (size_t)idx[c] + 1, v[2 * c + 1]);
+                        }
+                }
+                // flush: 16 lanes per line, 4 lines per instruction, 16 lines per trip (loads first)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int sub = lane & 15;
+                for (uint32_t e0 = lane >> 4; e0 < used; e0 += 16) {
+                    uint32_t ent[4];
+                    float vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ent[u] = (e0 + 4 * u < used) ? list[e0 + 4 * u] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) vv[u] = (ent[u] != 0xFFFFFFFFu) ? val[(ent[u] & 255) * 16 + sub] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (vv[u] != 0.f && !(dbg & 1)) atomicAdd(dt + (size_t)(ent[u] >> 8) * 16 + sub, vv[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ent[u] != 0xFFFFFFFFu) {
+                            val[(ent[u] & 255) * 16 + sub] = 0.f;
+                            if (sub == 0) key[ent[u] & 255] = kNoLine;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (WITH_DX) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+            if (valid[r]) {
+                dx[si[r] * 3 + 0] = dacc[r][0];
+                dx[si[r] * 3 + 1] = dacc[r][1];
+                dx[si[r] * 3 + 2] = dacc[r][2];
+            }
+    }
 }
 
 int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
@@ -305,14 +586,31 @@ extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const f
     static const int rounds = getenv("LSE_HASH_BWD_ROUNDS") ? atoi(getenv("LSE_HASH_BWD_ROUNDS")) : 32;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
+    // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
+    static const int impl = getenv("LSE_HASH_BWD_IMPL") ? atoi(getenv("LSE_HASH_BWD_IMPL")) : 1;
+    bool lines_ok = true;
+    for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
+    static const int dbg = getenv("LSE_HASH_BWD_DBG") ? atoi(getenv("LSE_HASH_BWD_DBG")) : 0;   // timing experiments only
+    if (impl == 1 && lines_ok) {
+        constexpr int kSlots = 256, kR = 1;
+        const int64_t blocks = (n + 4 * 64 * kR - 1) / (4 * 64 * kR);
+        LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
+        const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
+        const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        if (dx) hipLaunchKernelGGL((hash_bwd_cached_kernel<true, kSlots, kR>), dim3((unsigned)blocks), dim3(256), 0, st, g,
+                                   x01, dy2, tb2, dtable, dx, n, dbg);
+        else hipLaunchKernelGGL((hash_bwd_cached_kernel<false, kSlots, kR>), dim3((unsigned)blocks), dim3(256), 0, st, g,
+                                x01, dy2, tb2, dtable, dx, n, dbg);
+        return lse::check_launch("lse_hash_bwd");
+    }
 #define LSE_LAUNCH_BWD(R)                                                                                             \
     do {                                                                                                              \
         const int64_t blocks = (n + 4 * 4 * R - 1) / (4 * 4 * R);                                                     \
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");                                            \
         if (dx) hipLaunchKernelGGL((hash_bwd_kernel<true, R>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy, tb, \
-                                   dtable, dx, n, il_scale);                                                          \
+                                   dtable, dx, n, il_scale, dbg);                                                     \
         else hipLaunchKernelGGL((hash_bwd_kernel<false, R>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy, tb,   \
-                                dtable, dx, n, il_scale);                                                             \
+                                dtable, dx, n, il_scale, dbg);                                                        \
     } while (0)
     if (rounds == 32) LSE_LAUNCH_BWD(32);
     else if (rounds == 64) LSE_LAUNCH_BWD(64);

@@ -50,6 +50,7 @@ struct MlpArgs {
     float *d_act0;      // nullable: layer-0 pre-activation gradients only (row-bias gradient)
     float *d_in;        // nullable
     float *d_params;    // nullable: fused weight gradients accumulate here
+    float *d_row_bias;  // nullable: gradient of row_bias, accumulated per row (needs row_bias_idx, rows contiguous)
     // fused density head (base MLP): sigma = density_scale * exp(out[:,0]) * selector
     float *sigma_out;            // fwd, nullable
     const uint8_t *selector;     // nullable (all in-bounds)
@@ -367,6 +368,37 @@ __device__ __forceinline__ void flush_wgrad(float *dw, int ld, int k_real, const
             }
 }
 
+// d(row_bias)[row] += sum over the samples of that row of the layer-0 pre-activation gradient.  Samples are sorted by
+// row (a ray's samples are contiguous), so inside one 16-sample column tile the rows form contiguous runs: a 16-lane
+// segmented inclusive scan leaves every run's total in its last lane, which adds 4 x 16 B per row block to d_row_bias
+// (one 64-B line request per (tile, row block) instead of a materialised [N, W] gradient + a second reduction pass).
+template <int HB, int WIDTH>
+__device__ __forceinline__ void row_bias_grad_tile(float *d_row_bias, int row, const f32x4 (&g)[HB], int j, int q)
+{
+    f32x4 v[HB];
+#pragma unroll
+    for (int rb = 0; rb < HB; ++rb) v[rb] = g[rb];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const int row_o = __shfl_up(row, off, 16);
+        const bool take = (j >= off) && (row_o == row);
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = __shfl_up(v[rb][r], off, 16);
+                v[rb][r] += take ? t : 0.f;
+            }
+    }
+    const int row_n = __shfl_down(row, 1, 16);
+    if (j == 15 || row_n != row) {
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&d_row_bias[(int64_t)row * WIDTH + 16 * rb + 4 * q + r], v[rb][r]);
+    }
+}
+
 template <int KIN, int WIDTH, int NHL, int INL, bool WGRAD, int CT, int NW>
 __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bwd_kernel(MlpArgs a)
 {
@@ -518,6 +550,16 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
                         if (a.d_act0) *reinterpret_cast<f32x4 *>(a.d_act0 + s[ct] * WIDTH + 16 * rb + 4 * q) = dh[rb][ct];
                     }
                 }
+        }
+        // ---- gradient of the per-row layer-0 bias
+        if (a.d_row_bias) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 gcol[HB];
+#pragma unroll
+                for (int rb = 0; rb < HB; ++rb) gcol[rb] = dh[rb][ct];      // zero for tail columns
+                row_bias_grad_tile<HB, WIDTH>(a.d_row_bias, a.row_bias_idx[s[ct]], gcol, j, q);
+            }
         }
         // ---- layer-0 weights: dW0[WIDTH x KIN] += dH_0^T * in
         if (WGRAD) wgrad_from_mem<HB, KIN, INL, CT>(acc0, tr, dh, a.in, n, tile_base, j, q);
@@ -854,7 +896,8 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
 extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act,
                            int32_t act_tiled, const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
                            const uint8_t *selector, float density_scale, float *d_out_pre, float *d_act, float *d_act0,
-                           float *d_in, float *d_params, int64_t n, lse_stream_t stream)
+                           float *d_in, float *d_params, const int32_t *row_bias_idx, float *d_row_bias, int64_t n,
+                           lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_bwd");
     if (rc) return rc;
@@ -865,6 +908,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     LSE_REQUIRE(!d_params || in, "lse_mlp_bwd: fused weight gradients need the layer-0 input `in`");
     LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_bwd: out_cols must be 16 or 4");
     LSE_REQUIRE(!d_sigma || out, "lse_mlp_bwd: the density gradient needs `out`");
+    LSE_REQUIRE(!d_row_bias || row_bias_idx, "lse_mlp_bwd: d_row_bias needs row_bias_idx (sorted rows)");
     LSE_REQUIRE(out_cols == 16 || !d_out_pre, "lse_mlp_bwd: d_out_pre needs the padded 16-column layout");
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
@@ -873,6 +917,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     a.density_scale = density_scale;
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
+    a.row_bias_idx = row_bias_idx; a.d_row_bias = d_row_bias;
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
 }

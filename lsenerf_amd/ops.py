@@ -299,7 +299,10 @@ class _MlpFn(torch.autograd.Function):
         d_out = _c(d_out) if d_out is not None else torch.zeros((n, out_cols), dtype=torch.float32, device=dev)
         d_sigma = _c(d_sigma) if d_sigma is not None else None
         need_bias = row_bias is not None and ctx.needs_input_grad[2]
-        d_act0 = torch.empty((n, meta.width), dtype=torch.float32, device=dev) if need_bias else None
+        # sorted row indices (packed samples): the kernel reduces the bias gradient per row itself
+        fused_bias = FUSED_BIAS_GRAD and need_bias and row_bias_idx is not None and bias_packed_info is not None
+        d_bias = torch.zeros_like(row_bias) if fused_bias else None
+        d_act0 = torch.empty((n, meta.width), dtype=torch.float32, device=dev) if (need_bias and not fused_bias) else None
         d_in = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         d_params = torch.zeros_like(params) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
@@ -309,7 +312,8 @@ class _MlpFn(torch.autograd.Function):
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
                       ctx.act_tiled, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
-                      _f32(d_params, "d_params", True), n, _stream())
+                      _f32(d_params, "d_params", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True) if fused_bias
+                      else None, _f32(d_bias, "d_bias", True), n, _stream())
         else:   # reference structure: materialise d_act, then one G^T A reduction per layer (padded outputs only)
             assert out_cols == 16
             d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
@@ -317,13 +321,13 @@ class _MlpFn(torch.autograd.Function):
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
                       0, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()), None,
-                      _f32(d_in, "d_in", True), None, n, _stream())
+                      _f32(d_in, "d_in", True), None, None, None, n, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
                       ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
                       ctypes.c_void_p(d_params.data_ptr()), n, _stream())
             d_act0 = d_act[0] if need_bias else None
-        d_bias = None
-        if need_bias:
+            fused_bias, d_bias = False, None
+        if need_bias and not fused_bias:
             if row_bias_idx is None:
                 d_bias = d_act0
             elif bias_packed_info is not None:
@@ -337,6 +341,7 @@ class _MlpFn(torch.autograd.Function):
 
 
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
+FUSED_BIAS_GRAD = True   # per-row bias gradient reduced inside lse_mlp_bwd (False: d_act0 + lse_segment_sum_rows)
 ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store/load instruction); fused path only
 
 

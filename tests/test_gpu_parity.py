@@ -228,6 +228,49 @@ def test_mlp_head_shape_with_ray_bias(N):
     _mlp_case(16, 64, 3, 16, "Sigmoid", False, N, True)
 
 
+@pytest.mark.parametrize("fused_wgrad,tiled,fused_bias", [(True, False, True), (True, True, False), (False, False, False)])
+def test_mlp_backward_variants_agree(monkeypatch, fused_wgrad, tiled, fused_bias):
+    """The in-library cross-checks: row-major saved activations, d_act0 + lse_segment_sum_rows, unfused lse_mlp_wgrad."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "FUSED_WGRAD", fused_wgrad)
+    monkeypatch.setattr(ops, "ACT_TILED", tiled)
+    monkeypatch.setattr(ops, "FUSED_BIAS_GRAD", fused_bias)
+    _mlp_case(16, 64, 3, 16, "Sigmoid", False, 2051, True, seed=3)
+    _mlp_case(32, 64, 2, 16, None, True, 2051, False, seed=4)
+
+
+def test_mlp_row_bias_grad_many_short_rows():
+    """Rows of 0..3 samples: several row boundaries inside every 16-sample tile of the fused bias-gradient scan."""
+    ops = _ops()
+    from lsenerf_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    N, R, W = 3001, 2000, 64
+    ridx = torch.sort(torch.randint(0, R, (N,), generator=g)).values
+    cnt = torch.bincount(ridx, minlength=R)
+    packed = torch.stack([torch.cumsum(cnt, 0) - cnt, cnt], -1)
+    meta = ops.MlpMeta(16, W, 2, _lib.LSE_ACT_NONE, _lib.LSE_IN_ROWMAJOR)
+    params = (torch.randn(16 * W + W * W + W * 16, generator=g) * 0.2)
+    x = torch.randn(N, 16, generator=g)
+    bias = torch.randn(R, W, generator=g)
+    grads = []
+    for fused in (True, False):
+        ops.FUSED_BIAS_GRAD = fused
+        try:
+            b = bias.clone().cuda().requires_grad_(True)
+            out = ops.fused_mlp(params.cuda(), x.cuda(), meta, N, b, ridx.int().cuda(), packed.cuda())
+            (out * out).sum().backward()
+        finally:
+            ops.FUSED_BIAS_GRAD = True
+        grads.append(b.grad.cpu())
+    # reference: torch autograd on the same maths
+    Wm = [params[:16 * W].view(W, 16), params[16 * W:16 * W + W * W].view(W, W), params[16 * W + W * W:].view(16, W)]
+    bc = bias.clone().requires_grad_(True)
+    h = torch.relu(x @ Wm[0].t() + bc[ridx]); h = torch.relu(h @ Wm[1].t()); o = h @ Wm[2].t()
+    (o * o).sum().backward()
+    assert nmax_err(grads[0], bc.grad) < TOL_GRAD and nmax_err(grads[1], bc.grad) < TOL_GRAD
+    assert torch.all(grads[0][cnt == 0] == 0)
+
+
 def test_mlp_config1_shapes():
     _mlp_case(8, 32, 2, 16, None, True, 777, False)          # L=4 hash grid -> 2x32 base MLP (BASELINE config 1)
     _mlp_case(16, 32, 3, 16, "Sigmoid", False, 777, True)

@@ -54,3 +54,28 @@ for C in (64, 256, 1024):
             blk = idx[w * C:(w + 1) * C].reshape(-1)
             tl += len(np.unique(blk >> 3)); te += len(np.unique(blk))
     print(f"chunk {C:5d} samples: distinct lines/sample {tl / N:.2f}, distinct entries/sample {te / N:.2f}")
+
+# ---- line-cache policy of hash_bwd_cached_kernel: 64-sample chunks, run ends only, 256 slots, one probe
+def cache_policy(slotfn, name, NS=256):
+    tl = tf = 0.0
+    for l in range(16):
+        scale = np.float32(meta.scales[l])
+        p = np.floor((x01.numpy() * scale + np.float32(0.5)).astype(np.float32)).astype(np.int64)
+        idx = hg.tcnn_corner_indices(x01, meta, l).numpy()
+        lines = fb = 0
+        for w in range(N // 64):
+            pp, ii = p[w * 64:(w + 1) * 64], idx[w * 64:(w + 1) * 64]
+            same = np.concatenate([[False], (pp[1:] == pp[:-1]).all(1)])
+            ends = np.concatenate([~same[1:], [True]])
+            pe, ie = pp[ends], ii[ends]
+            keys = {}
+            for c in range(8):
+                sl = slotfn(pe[:, 0] + (c & 1), pe[:, 1] + ((c >> 1) & 1), pe[:, 2] + (c >> 2), ie[:, c] >> 3)
+                for s_, ln in zip(sl, ie[:, c] >> 3):
+                    k = keys.get(s_)
+                    if k is None: keys[s_] = ln; lines += 1
+                    elif k != ln: fb += 1
+        tl += lines / N; tf += fb / N
+    print(f"line cache ({name}): flushed lines/sample {tl:.2f} + direct-to-memory updates/sample {tf:.2f}")
+cache_policy(lambda x, y, z, ln: ((ln * 0x9E3779) >> 16) & 255, "multiplicative hash")
+cache_policy(lambda x, y, z, ln: ((x >> 3) * 7 + y * 19 + z * 83) & 255, "linear in cell coordinates")
