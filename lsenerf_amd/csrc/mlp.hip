@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
     constexpr int RB0 = (KIN + 15) / 16;
     constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
-    constexpr int NP0 = WIDTH * KIN, NP1 = (NHL - 1) * WIDTH * WIDTH, NPO = 16 * WIDTH;
+    constexpr int NP0 = WIDTH * KIN, NP1 = (NHL - 1) * WIDTH * WIDTH;
     extern __shared__ float lds[];
     float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
     float *tr_all = imgI + IMGI * 64;                       // NW waves x kTrWave (WGRAD only)
@@ -453,11 +453,13 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     const int64_t n_tiles = (n + TS - 1) / TS;
     const float *act_last = a.act + (int64_t)(NHL - 1) * a.act_layer_stride;
     float *dact_last = a.d_act ? a.d_act + (int64_t)(NHL - 1) * n * WIDTH : nullptr;
-    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+    // One tile ahead: the raw operands of the NEXT tile (output gradient, saved last-layer activations, the output
+    // values the activation / density backward needs) are requested before the current tile's MFMA work starts -- the
+    // fused-wgrad kernel runs one wave per SIMD, so nothing else would hide that latency.
+    const bool need_out = a.out_activation == LSE_ACT_SIGMOID;
+    auto fetch = [&](int64_t tile, int64_t (&s)[CT], bool (&valid)[CT], f32x4 (&g)[1][CT], f32x4 (&ov)[CT], float (&dsg)[CT],
+                     f32x4 (&hv)[HB][CT]) {
         const int64_t tile_base = tile * TS;
-        int64_t s[CT];
-        bool valid[CT];
-        f32x4 g[1][CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int64_t si = tile_base + ct * 16 + j;
@@ -465,28 +467,56 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
             s[ct] = valid[ct] ? si : n - 1;
             if (a.out_cols == 16) g[0][ct] = *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 16 + 4 * q);
             else g[0][ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(a.d_out + s[ct] * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (a.out_activation == LSE_ACT_SIGMOID) {
-                f32x4 ov;
-                if (a.out_cols == 16) ov = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
-                else ov = (q == 0) ? *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[0][ct][r] = g[0][ct][r] * ov[r] * (1.f - ov[r]);
+            ov[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (need_out) {
+                if (a.out_cols == 16) ov[ct] = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 16 + 4 * q);
+                else if (q == 0) ov[ct] = *reinterpret_cast<const f32x4 *>(a.out + s[ct] * 4);
             }
+            dsg[ct] = 0.f;
             if (a.d_sigma && q == 0) {   // trunc_exp backward: d out0 += d_sigma * scale * exp(clamp(out0, -15, 15)) * selector
                 const bool in_bounds = a.selector == nullptr || a.selector[s[ct]] != 0;
-                const float x0 = fminf(fmaxf(a.out[s[ct] * a.out_cols], -15.f), 15.f);
-                if (in_bounds) g[0][ct][0] += a.d_sigma[s[ct]] * a.density_scale * expf(x0);
+                if (!need_out) ov[ct][0] = a.out[s[ct] * a.out_cols];
+                dsg[ct] = in_bounds ? a.d_sigma[s[ct]] : 0.f;
             }
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(act_last + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
+        }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * NW;
+    int64_t s[CT], s_n[CT];
+    bool valid[CT], valid_n[CT];
+    f32x4 g[1][CT], g_n[1][CT], ov[CT], ov_n[CT], hv[HB][CT], hv_n[HB][CT];
+    float dsg[CT], dsg_n[CT];
+    // (the two-hidden-layer kernel already uses all 256 registers a wave gets at 8 waves per CU: it fetches in place)
+    constexpr bool PF = (NHL == 1);
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    if (PF && tile < n_tiles) fetch(tile, s_n, valid_n, g_n, ov_n, dsg_n, hv_n);
+    for (; tile < n_tiles; tile += tile_stride) {
+        const int64_t tile_base = tile * TS;
+        if (!PF) fetch(tile, s_n, valid_n, g_n, ov_n, dsg_n, hv_n);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            s[ct] = s_n[ct];
+            valid[ct] = valid_n[ct];
+            g[0][ct] = g_n[0][ct];
+            ov[ct] = ov_n[ct];
+            dsg[ct] = dsg_n[ct];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) hv[rb][ct] = hv_n[rb][ct];
+        }
+        if (PF && tile + tile_stride < n_tiles) fetch(tile + tile_stride, s_n, valid_n, g_n, ov_n, dsg_n, hv_n);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float x0 = fminf(fmaxf(ov[ct][0], -15.f), 15.f);   // lanes q == 0 hold out[s][0]
+            if (need_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[0][ct][r] = g[0][ct][r] * ov[ct][r] * (1.f - ov[ct][r]);
+            }
+            if (a.d_sigma && q == 0) g[0][ct][0] += dsg[ct] * a.density_scale * expf(x0);
             if (!valid[ct]) g[0][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};   // tail columns contribute nothing downstream
             if (a.d_out_pre && valid[ct]) *reinterpret_cast<f32x4 *>(a.d_out_pre + s[ct] * 16 + 4 * q) = g[0][ct];
         }
-        // ---- saved activations of the last hidden layer (ReLU mask and, for WGRAD, the B side of dWo)
-        f32x4 hv[HB][CT];
-#pragma unroll
-        for (int rb = 0; rb < HB; ++rb)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(act_last + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
         // ---- output-layer weights: dWo[16 x WIDTH] += g^T * act_last
         if (WGRAD) wgrad_from_regs<1, HB, CT>(accO, tr, g, hv, j, q);
         // ---- dH_last

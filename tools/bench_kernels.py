@@ -62,6 +62,14 @@ def main():
             pg = p.clone().requires_grad_(True)
             med, mn = timeit(lambda: ops.fused_mlp(pg, xin, meta, N, out_cols=4 if name == "head" else 16))
             print(f"mlp_fwd {name} (act saved)   median {med:.3f} ms", flush=True)
+            xg = xin.clone().requires_grad_(True)
+            out = ops.fused_mlp(pg, xg, meta, N, out_cols=4 if name == "head" else 16)
+            go = torch.randn_like(out)
+            def bwd():
+                pg.grad = None; xg.grad = None
+                out.backward(go, retain_graph=True)
+            med, mn = timeit(bwd)
+            print(f"mlp_bwd {name} (autograd backward incl. zero-fills) median {med:.3f} ms  min {mn:.3f}", flush=True)
     if want("traverse"):
         from lsenerf_amd import LSEOccGridEstimator
         est = LSEOccGridEstimator([-1, -1, -1, 1, 1, 1], 128, 4).to(dev); est.mark_all_occupied()
