@@ -260,16 +260,19 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
 //   * consecutive lanes that sit in the same cell form a run; a flag-based segmented scan (DPP inside the 16-lane rows,
 //     early exit once no run is longer than the step, serial carry over the 3 row borders) leaves each run's 8 x 2
 //     corner sums in the run's last lane;
-//   * run ends add into a per-wave LDS cache of table LINES (key = entry index >> 3, payload 16 floats = one 64-B line
-//     of 8 entries x 2 features; 256 slots, one probe): 32-bit compare-and-swap claims the slot, a 64-bit
+//   * run ends add into a per-wave LDS cache of table SECTORS (key = entry index >> 2, payload 8 floats = one 32-B
+//     sector of 4 entries x 2 features; 512 slots, one probe): a 32-bit compare-and-swap claims the slot, a 64-bit
 //     compare-and-swap adds both features (ds_add_f32 runs at ~3 cycles per LANE on gfx950, tools/micro/lds_ops.hip);
-//     a corner whose slot belongs to another line goes straight to memory, so the cache is purely an optimisation;
-//   * after each level the occupied slots (kept in a list) are flushed with one 16-lane x 64-B atomic per line.
-//   Modelled requests per sample (tools/sim_hash_bwd_requests.py): 7.7 lines + 4.1 direct = 11.8 instead of 19
-//   (9.2 with a collision-free cache).  4.37 -> 3.54 ms; what remains is instruction issue (rocprof: VALU+SALU+LDS
-//   issue ~ 75 % of the SIMD cycles at the 2 waves/SIMD the 75 KB of LDS allow) plus ~2.4 ms of atomics underneath.
-//   Tried and dropped: more probe rounds (each costs more issue slots than its saved requests), two half-wave
-//   phases per fine level, ds_add_f32 payload adds, a slot function linear in the cell coordinates.
+//     a corner whose slot belongs to another sector goes straight to memory, so the cache is purely an optimisation;
+//   * after each level the occupied slots (kept in a list) are flushed with one 8-lane x 32-B atomic per sector.
+//   The memory-side atomic units are priced per 32-B sector request at ~20 G/s (rocprof WRITE_SIZE / 32 B tracks the
+//   kernel time).  tools/sim_hash_bwd_requests.py models the policy: 256 slots of a 64-B line flush 9.1 sectors per
+//   sample and send 4.2 corner updates straight to memory (two 4-B atomics each; measured 16.5 sector writes per
+//   sample, 3.54 ms); 512 sector-sized slots in the same 16 KB collide less: 9.8 + 2.6 (3.23 ms).  The kernel above
+//   writes 21 per sample (4.37 ms).  Tried and dropped: more probe rounds (each costs more issue slots than its saved
+//   requests -- the kernel is close to issue-bound as well: VALU+SALU+LDS issue ~ 75 % of the SIMD cycles at the
+//   2 waves/SIMD that 79 KB of LDS allow), two half-wave phases per fine level, ds_add_f32 payload adds, a slot function
+//   linear in the cell coordinates.
 constexpr uint32_t kNoLine = 0xFFFFFFFFu;
 
 // LDS pointers carry their address space so that every cache access is a ds_* instruction (generic pointers make the
@@ -324,33 +327,35 @@ __device__ __forceinline__ bool seg_scan_row_step(float (&v)[16], int &flag, int
     return true;
 }
 
-template <bool WITH_DX, int kSlots, int kRounds>
+template <bool WITH_DX, int kSlots, int kEntLog2>
 __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
                                                               int64_t n, int dbg)
 {
-    static_assert(kRounds == 1, "one 64-sample round per wave");
+    constexpr int kRounds = 1;                 // one 64-sample round per wave
+    constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
+    constexpr int kPay = 2 * kEnt;             // payload floats per slot = lanes per slot in the flush
+    constexpr int kSlotBits = 31 - __builtin_clz((unsigned)kSlots);
     constexpr int kChunk = 64 * kRounds;
     __shared__ uint32_t s_key[4][kSlots];
-    __shared__ float s_val[4][kSlots * 16];
-    __shared__ uint32_t s_list[4][kSlots];      // (line << 8) | slot of every occupied slot
+    __shared__ float s_val[4][kSlots * kPay];
+    __shared__ uint16_t s_list[4][kSlots];      // occupied slots
     __shared__ uint32_t s_dummy32[4][64];
     __shared__ uint64_t s_dummy64[4][64];
-    static_assert(kSlots <= 256, "slot id is packed into 8 bits");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
     if (wave_base >= n) return;
     lds_u32 *key = (lds_u32 *)&s_key[wave][0];
     lds_f32 *val = (lds_f32 *)&s_val[wave][0];
-    lds_u32 *list = (lds_u32 *)&s_list[wave][0];
+    lds_u16 *list = (lds_u16 *)&s_list[wave][0];
     lds_u32 *dummy32 = (lds_u32 *)&s_dummy32[wave][lane];
     lds_u64 *dummy64 = (lds_u64 *)&s_dummy64[wave][lane];
     *dummy32 = kNoLine;
     *dummy64 = 0;
     for (int s = lane; s < kSlots; s += 64) key[s] = kNoLine;
-    for (int s = lane; s < kSlots * 16; s += 64) val[s] = 0.f;
+    for (int s = lane; s < kSlots * kPay; s += 64) val[s] = 0.f;
 
     float px[kRounds][3], dacc[kRounds][3];
     int64_t si[kRounds];
@@ -451,10 +456,10 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                     // collisions on ray-shaped line sets, tools/sim_hash_bwd_requests.py)
                     uint32_t slot[8], old[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) slot[c] = (__umul24(idx[c] >> 3, 0x9E3779u) >> 16) & (kSlots - 1);
+                    for (int c = 0; c < 8; ++c) slot[c] = (__umul24(idx[c] >> kEntLog2, 0x9E3779u) >> (24 - kSlotBits)) & (kSlots - 1);
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (idx[c] >> 3) : kNoLine);
+                        old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (idx[c] >> kEntLog2) : kNoLine);
                     // float LDS atomics run at ~3 cycles per LANE on gfx950 (tools/micro/lds_ops.hip: ds_add_f32 194 cycles
                     // per instruction, ds_cmpst_b64 22): add both features with one 64-bit compare-and-swap
                     lds_u64 *va[8];
@@ -467,12 +472,12 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                         if (cm) {
                             if (claim)
                                 list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                    ((idx[c] >> 3) << 8) | slot[c];
+                                    (uint16_t)slot[c];
                             used += __builtin_popcountll(cm);
                         }
-                        const bool ok = claim || (act && old[c] == (idx[c] >> 3));
+                        const bool ok = claim || (act && old[c] == (idx[c] >> kEntLog2));
                         to_mem[c] = act && !ok;
-                        va[c] = ok ? (lds_u64 *)&val[slot[c] * 16 + (idx[c] & 7) * 2] : dummy64;
+                        va[c] = ok ? (lds_u64 *)&val[slot[c] * kPay + (idx[c] & (kEnt - 1)) * 2] : dummy64;
                     }
 #pragma unroll
                     for (int c = 0; c < 8; ++c) cur[c] = *va[c];
@@ -499,22 +504,27 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                 // flush: 16 lanes per line, 4 lines per instruction, 16 lines per trip (loads first)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const int sub = lane & 15;
-                for (uint32_t e0 = lane >> 4; e0 < used; e0 += 16) {
-                    uint32_t ent[4];
+                constexpr int kPer = 64 / kPay;   // slots per flush instruction
+                const int sub = lane & (kPay - 1);
+                for (uint32_t e0 = lane / kPay; e0 < used; e0 += 4 * kPer) {
+                    uint32_t ent[4], ln[4];
                     float vv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ent[u] = (e0 + 4 * u < used) ? list[e0 + 4 * u] : 0xFFFFFFFFu;
+                    for (int u = 0; u < 4; ++u) ent[u] = (e0 + kPer * u < used) ? (uint32_t)list[e0 + kPer * u] : 0xFFFFFFFFu;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) vv[u] = (ent[u] != 0xFFFFFFFFu) ? val[(ent[u] & 255) * 16 + sub] : 0.f;
+                    for (int u = 0; u < 4; ++u) {
+                        ln[u] = (ent[u] != 0xFFFFFFFFu) ? key[ent[u]] : 0u;
+                        vv[u] = (ent[u] != 0xFFFFFFFFu) ? val[ent[u] * kPay + sub] : 0.f;
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (vv[u] != 0.f && !(dbg & 1)) atomicAdd(dt + (size_t)(ent[u] >> 8) * 16 + sub, vv[u]);
+                        if (vv[u] != 0.f && !(dbg & 1)) atomicAdd(dt + (size_t)ln[u] * kPay + sub, vv[u]);
+                    __builtin_amdgcn_wave_barrier();   // every lane of a slot has read the key before lane 0 resets it
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (ent[u] != 0xFFFFFFFFu) {
-                            val[(ent[u] & 255) * 16 + sub] = 0.f;
-                            if (sub == 0) key[ent[u] & 255] = kNoLine;
+                            val[ent[u] * kPay + sub] = 0.f;
+                            if (sub == 0) key[ent[u]] = kNoLine;
                         }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -592,15 +602,22 @@ extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const f
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
     static const int dbg = getenv("LSE_HASH_BWD_DBG") ? atoi(getenv("LSE_HASH_BWD_DBG")) : 0;   // timing experiments only
     if (impl == 1 && lines_ok) {
-        constexpr int kSlots = 256, kR = 1;
-        const int64_t blocks = (n + 4 * 64 * kR - 1) / (4 * 64 * kR);
+        static const int gran = getenv("LSE_HASH_BWD_GRAN") ? atoi(getenv("LSE_HASH_BWD_GRAN")) : 2;
+        const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
-        if (dx) hipLaunchKernelGGL((hash_bwd_cached_kernel<true, kSlots, kR>), dim3((unsigned)blocks), dim3(256), 0, st, g,
-                                   x01, dy2, tb2, dtable, dx, n, dbg);
-        else hipLaunchKernelGGL((hash_bwd_cached_kernel<false, kSlots, kR>), dim3((unsigned)blocks), dim3(256), 0, st, g,
-                                x01, dy2, tb2, dtable, dx, n, dbg);
+#define LSE_LAUNCH_CACHED(DX, SLOTS, ENTLOG2)                                                                          \
+    hipLaunchKernelGGL((hash_bwd_cached_kernel<DX, SLOTS, ENTLOG2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2, \
+                       tb2, dtable, dx, n, dbg)
+        if (gran == 2) {   // 512 slots of one 32-B sector
+            if (dx) LSE_LAUNCH_CACHED(true, 512, 2);
+            else LSE_LAUNCH_CACHED(false, 512, 2);
+        } else {           // 256 slots of one 64-B line
+            if (dx) LSE_LAUNCH_CACHED(true, 256, 3);
+            else LSE_LAUNCH_CACHED(false, 256, 3);
+        }
+#undef LSE_LAUNCH_CACHED
         return lse::check_launch("lse_hash_bwd");
     }
 #define LSE_LAUNCH_BWD(R)                                                                                             \

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     f32x4 g[1][CT], g_n[1][CT], ov[CT], ov_n[CT], hv[HB][CT], hv_n[HB][CT];
     float dsg[CT], dsg_n[CT];
     // (the two-hidden-layer kernel already uses all 256 registers a wave gets at 8 waves per CU: it fetches in place)
-    constexpr bool PF = (NHL == 1);
+    constexpr bool PF = (NHL == 1) || (NW == 4 && WGRAD);
     int64_t tile = (int64_t)blockIdx.x * NW + wave;
     if (PF && tile < n_tiles) fetch(tile, s_n, valid_n, g_n, ov_n, dsg_n, hv_n);
     for (; tile < n_tiles; tile += tile_stride) {
@@ -506,6 +506,14 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
             for (int rb = 0; rb < HB; ++rb) hv[rb][ct] = hv_n[rb][ct];
         }
         if (PF && tile + tile_stride < n_tiles) fetch(tile + tile_stride, s_n, valid_n, g_n, ov_n, dsg_n, hv_n);
+        f32x4 hv0[(PF && NHL == 2) ? HB : 1][CT];   // first-layer activations of THIS tile, requested before the MFMA work
+        if constexpr (PF && NHL == 2) {
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    hv0[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const float x0 = fminf(fmaxf(ov[ct][0], -15.f), 15.f);   // lanes q == 0 hold out[s][0]
@@ -549,8 +557,10 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    hv[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
+                for (int ct = 0; ct < CT; ++ct) {
+                    if constexpr (PF && NHL == 2) hv[rb][ct] = hv0[rb][ct];
+                    else hv[rb][ct] = *reinterpret_cast<const f32x4 *>(a.act + act_offset<WIDTH>(a.act_tiled, s[ct], rb, q));
+                }
             if constexpr (WGRAD && NHL == 2) wgrad_from_regs<HB, HB, CT>(acc1, tr, dh, hv, j, q);
             f32x4 d0[HB][CT];
 #pragma unroll
@@ -835,6 +845,7 @@ int launch_bwd(const MlpArgs &a, hipStream_t st)
     static const int cfg = env_int("LSE_MLP_BWD_CFG", 28);   // CT*10 + NW
     switch (cfg) {
     case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
+    case 24: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 4>(a, st);
     case 216: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
     case 116: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 1, 16>(a, st);
     default: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);

@@ -55,27 +55,34 @@ for C in (64, 256, 1024):
             tl += len(np.unique(blk >> 3)); te += len(np.unique(blk))
     print(f"chunk {C:5d} samples: distinct lines/sample {tl / N:.2f}, distinct entries/sample {te / N:.2f}")
 
-# ---- line-cache policy of hash_bwd_cached_kernel: 64-sample chunks, run ends only, 256 slots, one probe
-def cache_policy(slotfn, name, NS=256):
+# ---- cache policy of hash_bwd_cached_kernel: 64-sample chunks, run ends only, one probe.  Cost unit = 32-B sectors
+# reaching the memory-side atomic units (rocprof WRITE_SIZE / 32 B matches this count: 16.5 per sample for the
+# 256 x 64-B variant, measured 2.17 GKiB per launch).
+def cache_policy(ent_log2, n_slots, name, slotfn=None):
     tl = tf = 0.0
     for l in range(16):
         scale = np.float32(meta.scales[l])
         p = np.floor((x01.numpy() * scale + np.float32(0.5)).astype(np.float32)).astype(np.int64)
         idx = hg.tcnn_corner_indices(x01, meta, l).numpy()
-        lines = fb = 0
+        sect = fb = 0
         for w in range(N // 64):
             pp, ii = p[w * 64:(w + 1) * 64], idx[w * 64:(w + 1) * 64]
             same = np.concatenate([[False], (pp[1:] == pp[:-1]).all(1)])
             ends = np.concatenate([~same[1:], [True]])
             pe, ie = pp[ends], ii[ends]
-            keys = {}
+            keys, flushed = {}, set()
             for c in range(8):
-                sl = slotfn(pe[:, 0] + (c & 1), pe[:, 1] + ((c >> 1) & 1), pe[:, 2] + (c >> 2), ie[:, c] >> 3)
-                for s_, ln in zip(sl, ie[:, c] >> 3):
+                gran = ie[:, c] >> ent_log2
+                sl = slotfn(pe[:, 0] + (c & 1), pe[:, 1] + ((c >> 1) & 1), pe[:, 2] + (c >> 2), gran) if slotfn else \
+                    ((gran * 0x9E3779) >> (24 - int(np.log2(n_slots)))) & (n_slots - 1)
+                for s_, gk, e in zip(sl, gran, ie[:, c]):
                     k = keys.get(s_)
-                    if k is None: keys[s_] = ln; lines += 1
-                    elif k != ln: fb += 1
-        tl += lines / N; tf += fb / N
-    print(f"line cache ({name}): flushed lines/sample {tl:.2f} + direct-to-memory updates/sample {tf:.2f}")
-cache_policy(lambda x, y, z, ln: ((ln * 0x9E3779) >> 16) & 255, "multiplicative hash")
-cache_policy(lambda x, y, z, ln: ((x >> 3) * 7 + y * 19 + z * 83) & 255, "linear in cell coordinates")
+                    if k is None: keys[s_] = gk; flushed.add(e >> 2)
+                    elif k == gk: flushed.add(e >> 2)
+                    else: fb += 1
+            sect += len(flushed)
+        tl += sect / N; tf += fb / N
+    print(f"cache {name}: flushed sectors/sample {tl:.2f} + direct-to-memory updates/sample {tf:.2f} = {tl + tf:.2f}")
+cache_policy(3, 256, "256 slots x 64-B line, multiplicative hash")
+cache_policy(3, 256, "256 slots x 64-B line, slot linear in cell coordinates", lambda x, y, z, g: ((x >> 3) * 7 + y * 19 + z * 83) & 255)
+cache_policy(2, 512, "512 slots x 32-B sector, multiplicative hash (default)")
