@@ -312,6 +312,9 @@ __device__ __forceinline__ int row_shr_i32(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true);
 }
 
+// lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ int quad_swap1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+
 // One step of the flag-based segmented inclusive scan inside the 16-lane rows (pure VALU: DPP operand + fma).
 // Returns false (wave-uniform) when no lane needs this or any later step.
 template <int OFF>
@@ -494,12 +497,21 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                                 prev[c] = lds_cas(va[c], cur[c], add_pair(cur[c], v[2 * c], v[2 * c + 1]));
                             }
                     }
+                    // Corners whose slot is owned by another sector go straight to memory.  The two features of an entry are
+                    // written by a PAIR of lanes in one instruction (lane and lane^1 swap operands through DPP), so the
+                    // 8 bytes cost one request to the atomic units instead of two.
+                    const bool is_odd = lane & 1;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (to_mem[c]) {   // slot owned by another line: straight to memory
-                            atomicAdd(dt + 2 * (size_t)idx[c], v[2 * c]);
-                            atomicAdd(dt + 2 * (size_t)idx[c] + 1, v[2 * c + 1]);
-                        }
+                    for (int c = 0; c < 8; ++c) {
+                        if (__builtin_amdgcn_ballot_w64(to_mem[c]) == 0) continue;
+                        const uint32_t idx_n = (uint32_t)quad_swap1((int)idx[c]);
+                        const float v0_n = __int_as_float(quad_swap1(__float_as_int(v[2 * c])));
+                        const float v1_n = __int_as_float(quad_swap1(__float_as_int(v[2 * c + 1])));
+                        const bool tm_n = quad_swap1((int)to_mem[c]) != 0;
+                        // first instruction serves the even lanes' corners, second one the odd lanes'
+                        if (is_odd ? tm_n : to_mem[c]) atomicAdd(dt + 2 * (size_t)(is_odd ? idx_n : idx[c]) + is_odd, is_odd ? v1_n : v[2 * c]);
+                        if (is_odd ? to_mem[c] : tm_n) atomicAdd(dt + 2 * (size_t)(is_odd ? idx[c] : idx_n) + is_odd, is_odd ? v[2 * c + 1] : v0_n);
+                    }
                 }
                 // flush: 16 lanes per line, 4 lines per instruction, 16 lines per trip (loads first)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
