@@ -141,7 +141,8 @@ def main():
 
     # timed region: barrier + synchronize on both sides, per-kernel HIP events on the launch stream
     _lib.TIMING = {"names": {"lse_hash_bwd", "lse_hash_fwd", "lse_mlp_fwd", "lse_mlp_bwd", "lse_mlp_wgrad",
-                             "lse_volrend_fwd", "lse_volrend_bwd", "lse_traverse_grids", "lse_adam_step"}, "events": []}
+                             "lse_volrend_fwd", "lse_volrend_bwd", "lse_traverse_grids", "lse_traverse_grids_slots",
+                             "lse_compact_ray_slots", "lse_adam_step"}, "events": []}
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()

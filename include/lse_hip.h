@@ -81,6 +81,19 @@ int lse_traverse_grids(const float *rays_o, const float *rays_d, int32_t n_rays,
                        int32_t mode, int64_t *chunk_cnts, const int64_t *chunk_starts, int32_t *ray_indices,
                        float *t_starts, float *t_ends, lse_stream_t stream);
 
+/* Single-pass variant of the same traversal (same arithmetic, same samples): ray r writes its (t_start, t_end) pairs into
+ * the fixed-capacity slots [r*cap, (r+1)*cap) and its count into chunk_cnts[r]; *overflow is OR-ed with 1 if a ray
+ * produced more than cap samples (the caller then falls back to the two-pass calls above).  The host bound
+ * cap >= (t_exit - t_enter) / step_size + slack holds because every sample interval is at least step_size long.
+ * lse_compact_ray_slots packs the slots: ray_indices / t_starts / t_ends [N] at packed_info[r] = (start, count). */
+int lse_traverse_grids_slots(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
+                             const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
+                             const float *near_planes, const float *far_planes, float step_size, float cone_angle,
+                             int64_t cap, int64_t *chunk_cnts, float *t_start_slots, float *t_end_slots,
+                             int32_t *overflow, lse_stream_t stream);
+int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, int64_t cap, const int64_t *packed_info,
+                          int32_t n_rays, int32_t *ray_indices, float *t_starts, float *t_ends, lse_stream_t stream);
+
 /* nerfacc.pack_info (R:lse_nerf/lsenerf.py:300): packed_info[R,2] = (exclusive cumsum, count); total[1]. */
 int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info, int64_t *total,
                               lse_stream_t stream);

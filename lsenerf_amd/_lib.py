@@ -35,6 +35,8 @@ I32, I64, F32 = c_int32, c_int64, c_float
 # name -> argtypes (all return int except the two misc functions); mirrors include/lse_hip.h one to one
 SIGNATURES = {
     "lse_traverse_grids": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I32, P, P, P, P, P, P],
+    "lse_traverse_grids_slots": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I64, P, P, P, P, P],
+    "lse_compact_ray_slots": [P, P, I64, P, I32, P, P, P, P],
     "lse_pack_info_from_counts": [P, I32, P, P, P],
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],

@@ -42,6 +42,7 @@ __device__ __forceinline__ LevelInfo level_info(const GridParams &g, int l)
     li.res = g.res[l];
     li.scale = g.scales[l];
     // tcnn grid_index(): stride loop guarded by stride <= hashmap_size; hash iff hashmap_size < final stride
+    // (computed here with scalar instructions: fetching precomputed per-level flags from the kernel arguments was slower)
     uint64_t stride = 1;
     for (int d = 0; d < 3 && stride <= li.size; ++d) stride *= li.res;
     li.dense = !(li.size < stride);

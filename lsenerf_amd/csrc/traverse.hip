@@ -33,6 +33,8 @@ struct TraverseArgs {
     const int64_t *chunk_starts;
     int32_t *ray_indices;
     float *t_starts, *t_ends;
+    int64_t cap;          // MODE 2: samples of ray r go to slots [r*cap, (r+1)*cap)
+    int32_t *overflow;    // MODE 2: set when a ray produced more than cap samples (never, by the host's bound)
 };
 
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
@@ -73,7 +75,9 @@ __device__ bool slab(const float o[3], const float inv[3], const float *__restri
     return true;
 }
 
-template <bool WRITE, bool CONST_DT>
+// MODE 0: count per ray; 1: write at chunk_starts (second pass of the published two-pass scheme);
+// 2: single pass -- write (t_start, t_end) into fixed-capacity per-ray slots AND count (lse_compact_ray_slots packs them).
+template <int MODE, bool CONST_DT>
 __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 {
     __shared__ float s_tt[kBatch];
@@ -124,7 +128,9 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
     // published loops never end; every loop below draws from this budget (never reached for sane inputs).
     int budget = 1 << 24;
     int64_t base = 0;
-    if (WRITE) base = a.chunk_starts[tid];
+    constexpr bool WRITE = MODE != 0;
+    if (MODE == 1) base = a.chunk_starts[tid];
+    if (MODE == 2) base = (int64_t)tid * a.cap;
     float t_last = ray_tmin;
     bool continuous = false;
     const int res[3] = {a.rx, a.ry, a.rz};
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 for (int b = 0; b < nb; ++b) {   // one interval per occupied cell
                     const float t_traverse = s_tt[b];
                     if ((occ_mask >> b) & 1u) {
-                        if (WRITE && lane == 0) {
-                            a.ray_indices[base + n_samples] = tid;
+                        if (WRITE && lane == 0 && (MODE == 1 || n_samples < a.cap)) {
+                            if (MODE == 1) a.ray_indices[base + n_samples] = tid;
                             a.t_starts[base + n_samples] = t_last;
                             a.t_ends[base + n_samples] = t_traverse;
                         }
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                     if (!reached) {
                         const float t_next = t_last + dt;
                         if (occ) {
-                            if (WRITE && lane == 0) {
-                                a.ray_indices[base + n_samples] = tid;
+                            if (WRITE && lane == 0 && (MODE == 1 || n_samples < a.cap)) {
+                                if (MODE == 1) a.ray_indices[base + n_samples] = tid;
                                 a.t_starts[base + n_samples] = t_last;
                                 a.t_ends[base + n_samples] = t_next;
                             }
@@ -265,7 +271,8 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             __syncthreads();   // the next batch overwrites the LDS slots
         }
     }
-    if (!WRITE && lane == 0) a.chunk_cnts[tid] = n_samples;
+    if (MODE != 1 && lane == 0) a.chunk_cnts[tid] = n_samples;
+    if (MODE == 2 && lane == 0 && n_samples > a.cap) atomicOr(a.overflow, 1);
 }
 
 // single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
@@ -296,6 +303,23 @@ __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t *__restri
     if (t == 1023 && total) *total = part[1023];
 }
 
+// Packs the per-ray slots of the single-pass marcher: one wave per ray copies its count samples to the packed position.
+__global__ __launch_bounds__(256) void compact_slots_kernel(const float *__restrict__ ts_slots, const float *__restrict__ te_slots,
+                                                            int64_t cap, const int64_t *__restrict__ packed_info, int n_rays,
+                                                            int32_t *__restrict__ ray_indices, float *__restrict__ t_starts,
+                                                            float *__restrict__ t_ends)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    const int64_t start = packed_info[2 * (int64_t)ray], cnt = packed_info[2 * (int64_t)ray + 1];
+    const float *src_s = ts_slots + (int64_t)ray * cap, *src_e = te_slots + (int64_t)ray * cap;
+    for (int64_t k = lane; k < cnt; k += 64) {
+        ray_indices[start + k] = ray;
+        t_starts[start + k] = src_s[k];
+        t_ends[start + k] = src_e[k];
+    }
+}
+
 }  // namespace
 
 extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
@@ -315,18 +339,54 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
     if (mode == 0) LSE_REQUIRE(chunk_cnts, "lse_traverse_grids: count pass needs chunk_cnts");
     if (mode == 1) LSE_REQUIRE(chunk_starts && ray_indices && t_starts && t_ends, "lse_traverse_grids: write pass needs outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends};
+                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr};
     const int blocks = n_rays;   // one wave per ray
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
     if (mode == 0) {
-        if (const_dt) hipLaunchKernelGGL((traverse_kernel<false, true>), dim3(blocks), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((traverse_kernel<false, false>), dim3(blocks), dim3(64), 0, st, a);
+        if (const_dt) hipLaunchKernelGGL((traverse_kernel<0, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((traverse_kernel<0, false>), dim3(blocks), dim3(64), 0, st, a);
     } else {
-        if (const_dt) hipLaunchKernelGGL((traverse_kernel<true, true>), dim3(blocks), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((traverse_kernel<true, false>), dim3(blocks), dim3(64), 0, st, a);
+        if (const_dt) hipLaunchKernelGGL((traverse_kernel<1, true>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((traverse_kernel<1, false>), dim3(blocks), dim3(64), 0, st, a);
     }
     return lse::check_launch("lse_traverse_grids");
+}
+
+extern "C" int lse_traverse_grids_slots(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
+                                        const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
+                                        const float *near_planes, const float *far_planes, float step_size,
+                                        float cone_angle, int64_t cap, int64_t *chunk_cnts, float *t_start_slots,
+                                        float *t_end_slots, int32_t *overflow, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_traverse_grids_slots: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(rays_o && rays_d && binaries && aabbs && near_planes && far_planes, "lse_traverse_grids_slots: null input");
+    LSE_REQUIRE(levels >= 1 && levels <= LSE_MAX_OCC_LEVELS, "lse_traverse_grids_slots: levels %d not in [1,%d]", levels,
+                LSE_MAX_OCC_LEVELS);
+    LSE_REQUIRE(rx > 0 && ry > 0 && rz > 0, "lse_traverse_grids_slots: bad resolution");
+    LSE_REQUIRE((int64_t)levels * rx * ry * rz < (1ll << 31), "lse_traverse_grids_slots: grid too large (levels*cells >= 2^31)");
+    LSE_REQUIRE(cap >= 1 && chunk_cnts && t_start_slots && t_end_slots && overflow, "lse_traverse_grids_slots: bad outputs");
+    TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
+                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow};
+    const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
+    hipStream_t st = lse::as_stream(stream);
+    if (const_dt) hipLaunchKernelGGL((traverse_kernel<2, true>), dim3(n_rays), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((traverse_kernel<2, false>), dim3(n_rays), dim3(64), 0, st, a);
+    return lse::check_launch("lse_traverse_grids_slots");
+}
+
+extern "C" int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, int64_t cap,
+                                     const int64_t *packed_info, int32_t n_rays, int32_t *ray_indices, float *t_starts,
+                                     float *t_ends, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_compact_ray_slots: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_start_slots && t_end_slots && packed_info && ray_indices && t_starts && t_ends && cap >= 1,
+                "lse_compact_ray_slots: null pointer");
+    hipLaunchKernelGGL(compact_slots_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_start_slots,
+                       t_end_slots, cap, packed_info, n_rays, ray_indices, t_starts, t_ends);
+    return lse::check_launch("lse_compact_ray_slots");
 }
 
 extern "C" int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info,

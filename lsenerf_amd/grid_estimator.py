@@ -56,6 +56,15 @@ class LSEOccGridEstimator(nn.Module):
     def _binaries_u8(self) -> Tensor:
         return self.binaries.view(torch.uint8)
 
+    def _max_span(self, near_plane: float, far_plane: float) -> float:
+        """Host-side upper bound of the t-range any ray can spend inside the grids: the diagonal of the outermost aabb,
+        clipped by the planes (lets ops.traverse_grids march in a single pass).  Cached per version of `aabbs`."""
+        ver = self.aabbs._version
+        if getattr(self, "_diag_cache", (None, None))[0] != ver:
+            box = self.aabbs[-1].detach().cpu()
+            self._diag_cache = (ver, float((box[3:] - box[:3]).norm()))
+        return max(0.0, min(self._diag_cache[1], float(far_plane) - float(near_plane))) + 1e-3 * self._diag_cache[1]
+
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
                  t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
@@ -76,7 +85,7 @@ class LSEOccGridEstimator(nn.Module):
             near_planes = near_planes + u * render_step_size
         ray_indices, t_starts, t_ends, packed_info = ops.traverse_grids(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes.contiguous(),
-            far_planes.contiguous(), render_step_size, cone_angle)
+            far_planes.contiguous(), render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane))
 
         # skip invisible space
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None) and t_starts.shape[0] > 0:

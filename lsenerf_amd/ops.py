@@ -117,23 +117,54 @@ class MlpMeta:
 # ----------------------------------------------------------------------------------------------------
 # sampler
 # ----------------------------------------------------------------------------------------------------
+MAX_SLOT_ELEMS = 1 << 28   # single-pass marcher: upper limit for R * cap (2 x 1 GiB of scratch)
+
+
 @torch.no_grad()
-def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float):
+def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
+                   max_span: float = None):
     """nerfacc.grid.traverse_grids as consumed at R:lse_nerf/lse_grid_estimator.py:93-106.
-    Returns (ray_indices int32 [N], t_starts [N], t_ends [N], packed_info int64 [R,2]).  One host sync (N)."""
+    Returns (ray_indices int32 [N], t_starts [N], t_ends [N], packed_info int64 [R,2]).  One host sync (N).
+
+    max_span: host-known upper bound of (t_exit - t_enter) over all rays (clipped by the planes and the outermost aabb).
+    With it the march runs ONCE into fixed-capacity per-ray slots (every sample interval is >= step_size long, so
+    cap = max_span / step_size + slack bounds the count) and a copy kernel packs them; without it (or when the slots
+    would be too large) the published count pass + write pass run."""
     R = rays_o.shape[0]
     L, rx, ry, rz = binaries.shape
     dev = rays_o.device
     cnts = torch.empty(R, dtype=torch.int64, device=dev)
     packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)   # [N, overflow flag of the single-pass marcher]
     args = (_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), R, _chk(binaries, torch.uint8, "binaries"),
             _f32(aabbs, "aabbs"), L, rx, ry, rz, _f32(near_planes, "near_planes"), _f32(far_planes, "far_planes"),
             float(step_size), float(cone_angle))
+    if SINGLE_PASS_MARCH and max_span is not None and step_size > 0 and R > 0:
+        cap = int(max_span / step_size) + 8
+        if 0 < cap and R * cap <= MAX_SLOT_ELEMS:
+            ts_slots = torch.empty(R * cap, dtype=torch.float32, device=dev)
+            te_slots = torch.empty(R * cap, dtype=torch.float32, device=dev)
+            flag = total[1:].view(torch.int32)    # low word of total[1]
+            _lib.call("lse_traverse_grids_slots", *args, cap, ctypes.c_void_p(cnts.data_ptr()),
+                      ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()),
+                      ctypes.c_void_p(flag.data_ptr()), _stream())
+            _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
+                      ctypes.c_void_p(total.data_ptr()), _stream())
+            n, overflow = (int(v) for v in total.tolist())
+            if not overflow:
+                ri = torch.empty(n, dtype=torch.int32, device=dev)
+                ts = torch.empty(n, dtype=torch.float32, device=dev)
+                te = torch.empty(n, dtype=torch.float32, device=dev)
+                if n > 0:
+                    _lib.call("lse_compact_ray_slots", ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()),
+                              cap, ctypes.c_void_p(packed.data_ptr()), R, ctypes.c_void_p(ri.data_ptr()),
+                              ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(te.data_ptr()), _stream())
+                return ri, ts, te, packed
+            total.zero_()   # bound violated (not expected): redo with the two-pass scheme
     _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, _stream())
     _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
-    n = int(total.item())
+    n = int(total[0].item())
     ri = torch.empty(n, dtype=torch.int32, device=dev)
     ts = torch.empty(n, dtype=torch.float32, device=dev)
     te = torch.empty(n, dtype=torch.float32, device=dev)
@@ -340,6 +371,7 @@ class _MlpFn(torch.autograd.Function):
         return d_params, d_in, d_bias, None, None, None, None, None, None, None
 
 
+SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 FUSED_BIAS_GRAD = True   # per-row bias gradient reduced inside lse_mlp_bwd (False: d_act0 + lse_segment_sum_rows)
 ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store/load instruction); fused path only

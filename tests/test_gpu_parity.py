@@ -40,6 +40,29 @@ def test_traverse_bit_exact(levels, res, cone, step):
     assert torch.equal(hte.cpu(), te), "t_ends differ bitwise"
 
 
+@pytest.mark.parametrize("levels,res,cone,step", [(1, 32, 0.0, 0.01), (4, 32, 0.004, 0.005), (4, 128, 0.0, 0.0034641)])
+def test_traverse_single_pass_equals_two_pass(levels, res, cone, step):
+    """The single-pass marcher (fixed-capacity ray slots + compaction) returns the two-pass result bit for bit; a violated
+    capacity bound is detected and falls back."""
+    from oracle import sampling as osamp
+    ops = _ops()
+    R = 257
+    o, d = random_rays(R, seed=levels + res)
+    b = random_binaries(levels, res, 0.4, seed=res + 1)
+    aabbs = torch.stack([osamp.enlarge_aabb(torch.tensor([-1.0, -1, -1, 1, 1, 1]), 2 ** i) for i in range(levels)]).cuda()
+    near = (torch.full((R,), 0.05) + torch.rand(R, generator=torch.Generator().manual_seed(2)) * step).cuda()
+    far = torch.full((R,), 1e3).cuda()
+    args = (o.cuda(), d.cuda(), b.cuda().view(torch.uint8), aabbs, near, far, step, cone)
+    two = ops.traverse_grids(*args)
+    diag = float((aabbs[-1, 3:] - aabbs[-1, :3]).norm())
+    one = ops.traverse_grids(*args, max_span=diag)
+    tiny = ops.traverse_grids(*args, max_span=10 * step)          # bound far too small -> overflow -> fallback
+    assert two[0].numel() > 100
+    for got in (one, tiny):
+        for a_, b_ in zip(got, two):
+            assert torch.equal(a_, b_)
+
+
 def test_traverse_edge_cases():
     from oracle import sampling as osamp
     ops = _ops()
