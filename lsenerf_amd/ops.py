@@ -266,6 +266,16 @@ def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contractio
 # ----------------------------------------------------------------------------------------------------
 # hash grid
 # ----------------------------------------------------------------------------------------------------
+def _direct_grad(p: torch.Tensor):
+    """Leaf parameter whose .grad is already allocated (optim.FlatParams keeps every .grad as a view of one flat, zeroed
+    buffer): the backward kernels accumulate straight into it -- the entry points accumulate anyway -- and the Function
+    returns None for that input, which saves a zero-fill plus an accumulate pass per parameter and step."""
+    if DIRECT_PARAM_GRADS and p.is_leaf and p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32 \
+            and p.grad.is_contiguous() and p.grad.shape == p.shape:
+        return p.grad
+    return None
+
+
 class _HashFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x01, table, meta: GridMeta):
@@ -284,12 +294,13 @@ class _HashFn(torch.autograd.Function):
         meta = ctx.meta
         n = x01.shape[0]
         dy = _c(dy)
-        dtable = torch.zeros_like(table)
+        direct = _direct_grad(table)
+        dtable = direct if direct is not None else torch.zeros_like(table)
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
         _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
                   ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
-        return dx, dtable, None
+        return dx, (None if direct is not None else dtable), None
 
 
 def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> torch.Tensor:
@@ -335,7 +346,8 @@ class _MlpFn(torch.autograd.Function):
         d_bias = torch.zeros_like(row_bias) if fused_bias else None
         d_act0 = torch.empty((n, meta.width), dtype=torch.float32, device=dev) if (need_bias and not fused_bias) else None
         d_in = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        d_params = torch.zeros_like(params) if ctx.needs_input_grad[0] else None
+        direct = _direct_grad(params) if (ctx.needs_input_grad[0] and (ctx.act_tiled or FUSED_WGRAD)) else None
+        d_params = direct if direct is not None else (torch.zeros_like(params) if ctx.needs_input_grad[0] else None)
         desc = meta.desc()
         scale = float(ctx.density_scale or 0.0)
         sel = _chk(selector, torch.uint8, "selector", True)
@@ -368,9 +380,10 @@ class _MlpFn(torch.autograd.Function):
                           ctypes.c_void_p(d_bias.data_ptr()), _stream())
             else:   # unsorted row indices: generic scatter-add (not on the hot path)
                 d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act0)
-        return d_params, d_in, d_bias, None, None, None, None, None, None, None
+        return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None
 
 
+DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated leaf .grad (see _direct_grad)
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 FUSED_BIAS_GRAD = True   # per-row bias gradient reduced inside lse_mlp_bwd (False: d_act0 + lse_segment_sum_rows)
