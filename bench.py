@@ -56,9 +56,32 @@ def build_workload(device, seed):
     return model, rb, target.to(device), jitter.to(device)
 
 
-def train_step(model, rb, target, jitter, opt, world):
+class GradPipeline:
+    """N > 1: the one all-reduce of step k runs asynchronously (RCCL's own stream) while step k+1 marches its rays.
+
+    The sampler reads the occupancy grid only -- no parameters, no gradients -- so `all-reduce(k) -> Adam(k)` can be
+    finished AFTER `sampler(k+1)` without changing a single value: the forward pass of step k+1 still sees the parameters
+    updated by step k.  `flush()` applies the update that is still in flight; bench.py calls it before the timed region
+    starts and before it ends, so exactly K optimizer steps (and K all-reduces) are inside the timed K steps."""
+
+    def __init__(self, opt, world):
+        self.opt, self.world, self.work = opt, world, None
+
+    def start(self):
+        from lsenerf_amd import dist as ldist
+        self.work = ldist.allreduce_grads(self.opt.flat.grad, async_op=True)
+        self.pending = True
+
+    def flush(self):
+        if getattr(self, "pending", False):
+            if self.work is not None:
+                self.work.wait()
+            self.opt.step(grad_scale=1.0 / self.world)
+            self.work, self.pending = None, False
+
+
+def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None):
     from lsenerf_amd import dist as ldist
-    opt.zero_grad()
     rb.origins.grad = None
     rb.directions.grad = None
     cfg = model.config
@@ -66,10 +89,18 @@ def train_step(model, rb, target, jitter, opt, world):
         rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         t_max=rb.fars.reshape(-1), render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
         alpha_thre=cfg.alpha_thre, jitter=jitter, return_packed=True)
+    if pipeline is not None:
+        pipeline.flush()           # all-reduce + Adam of the previous step, hidden behind the marcher above
+    opt.zero_grad()
     out = model.render_packed(rb, ri, ts, te, packed)
     loss = torch.nn.functional.mse_loss(out["rgb"], target)
     loss.backward()
-    if world > 1:
+    if pipeline is not None:
+        pipeline.start()
+        return ri.shape[0], loss
+    if exchange is not None:
+        exchange.finish()          # the fine levels' table gradients have been in flight since the middle of the hash backward
+    elif world > 1:
         ldist.allreduce_grads(opt.flat.grad)
     opt.step(grad_scale=1.0 / world)
     return ri.shape[0], loss
@@ -134,21 +165,36 @@ def main():
     flat = FlatParams(model.get_param_groups()["fields"])
     ldist.broadcast_params(flat.data)
     opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
+    # N > 1: the gradient all-reduce of step k is hidden behind the ray marcher of step k+1 (GradPipeline).
+    # LSE_BENCH_EXCHANGE=plain selects the single blocking all-reduce; =overlap / =split the two-launch hash backward of
+    # dist.OverlappedGradExchange (measured at N = 1: the second launch costs 0.28 ms, more than the exchange it hides).
+    exchange, pipeline = None, None
+    mode = os.environ.get("LSE_BENCH_EXCHANGE", "pipelined" if world > 1 else "plain")
+    if mode == "pipelined":
+        pipeline = GradPipeline(opt, world)
+    if mode in ("overlap", "split"):
+        grid = model.field.mlp_base_grid
+        exchange = ldist.OverlappedGradExchange(flat, grid.params, grid.meta.offsets, split_level=min(6, grid.meta.n_levels - 1))
+        exchange.install()
 
     n_samples = 0
     for _ in range(args.warmup):
-        n_samples, _ = train_step(model, rb, target, jitter, opt, world)
+        n_samples, _ = train_step(model, rb, target, jitter, opt, world, exchange, pipeline)
+    if pipeline is not None:
+        pipeline.flush()
 
     # timed region: barrier + synchronize on both sides, per-kernel HIP events on the launch stream
     _lib.TIMING = {"names": {"lse_hash_bwd", "lse_hash_fwd", "lse_mlp_fwd", "lse_mlp_bwd", "lse_mlp_wgrad",
                              "lse_volrend_fwd", "lse_volrend_bwd", "lse_traverse_grids", "lse_traverse_grids_slots",
-                             "lse_compact_ray_slots", "lse_adam_step"}, "events": []}
+                             "lse_compact_ray_slots", "lse_hash_bwd_levels", "lse_adam_step"}, "events": []}
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_samples, loss = train_step(model, rb, target, jitter, opt, world)
+        n_samples, loss = train_step(model, rb, target, jitter, opt, world, exchange, pipeline)
+    if pipeline is not None:
+        pipeline.flush()           # the K-th all-reduce + Adam belong to the timed K steps
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
@@ -185,7 +231,7 @@ def main():
                                    "32-d appearance embedding), 4096 rays/GPU x 1024 samples (4-level 128^3 grid fully "
                                    "occupied, constant step), fwd+bwd+Adam, grads w.r.t. rays included",
                        "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": SAMPLES_PER_RAY, "samples_per_step": n_samples,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "grad_exchange": mode},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples},

@@ -132,6 +132,13 @@ int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const float *table
 int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
                  float *dx, int64_t n, lse_stream_t stream);
 
+/* The same backward restricted to levels [level_begin, level_end); dx_accumulate != 0 adds this launch's share to dx.
+ * Lets the caller finish the fine levels' table gradients (most of the bytes) first and start their all-reduce while
+ * the remaining levels are still being computed (lsenerf_amd.dist.OverlappedGradExchange). */
+int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
+                        float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end,
+                        int64_t n, lse_stream_t stream);
+
 /* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
  * [n_hidden_layers][N][width] (what lse_mlp_wgrad reads); act_tiled = 1 -> tile-major, an opaque workspace of

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lse_ray_grad_reduce": [P, P, P, P, I32, P, P, P],
     "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P],
     "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P],
+    "lse_hash_bwd_levels": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P],
     "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
     "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, I64, P],
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],

@@ -20,6 +20,8 @@ namespace {
 
 struct GridParams {
     int n_levels;
+    int l_begin, l_end;   // backward only: levels [l_begin, l_end) of this launch
+    int dx_accumulate;    // backward only: dx += instead of dx = (second launch of a split backward)
     uint32_t offsets[LSE_MAX_GRID_LEVELS + 1];
     float scales[LSE_MAX_GRID_LEVELS];
     uint32_t res[LSE_MAX_GRID_LEVELS];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
     const uint32_t cx = corner & 1, cy = (corner >> 1) & 1, cz = (corner >> 2) & 1;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-    for (int l = 0; l < g.n_levels; ++l) {
+    for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
         const bool interleaved = li.scale >= interleave_from_scale;
         float *__restrict__ dt = dtable + 2 * (size_t)li.offset + f;
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
         for (int c = lane; c < kChunk; c += 64) {
             const int64_t i = wave_base + c;
             if (i < n) {
-                dx[i * 3 + 0] = s_dx[wave][0][LSE_SLOT(c)];
-                dx[i * 3 + 1] = s_dx[wave][1][LSE_SLOT(c)];
-                dx[i * 3 + 2] = s_dx[wave][2][LSE_SLOT(c)];
+                const float a0 = g.dx_accumulate ? dx[i * 3 + 0] : 0.f, a1 = g.dx_accumulate ? dx[i * 3 + 1] : 0.f,
+                            a2 = g.dx_accumulate ? dx[i * 3 + 2] : 0.f;
+                dx[i * 3 + 0] = a0 + s_dx[wave][0][LSE_SLOT(c)];
+                dx[i * 3 + 1] = a1 + s_dx[wave][1][LSE_SLOT(c)];
+                dx[i * 3 + 2] = a2 + s_dx[wave][2][LSE_SLOT(c)];
             }
         }
     }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the cache is private to this wave; DS ops of a wave execute in order
 
-    for (int l = 0; l < g.n_levels; ++l) {
+    for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
         float *__restrict__ dt = dtable + 2 * (size_t)li.offset;
         const float2 *__restrict__ tab = table + li.offset;
@@ -549,6 +553,11 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
             if (valid[r]) {
+                if (g.dx_accumulate) {
+                    dacc[r][0] += dx[si[r] * 3 + 0];
+                    dacc[r][1] += dx[si[r] * 3 + 1];
+                    dacc[r][2] += dx[si[r] * 3 + 2];
+                }
                 dx[si[r] * 3 + 0] = dacc[r][0];
                 dx[si[r] * 3 + 1] = dacc[r][1];
                 dx[si[r] * 3 + 2] = dacc[r][2];
@@ -563,6 +572,9 @@ int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
                 desc->n_levels);
     LSE_REQUIRE(desc->n_features == 2, "%s: only n_features == 2 is implemented (got %d)", who, desc->n_features);
     g.n_levels = desc->n_levels;
+    g.l_begin = 0;
+    g.l_end = desc->n_levels;
+    g.dx_accumulate = 0;
     for (int l = 0; l <= desc->n_levels; ++l) g.offsets[l] = desc->offsets[l];
     for (int l = 0; l < desc->n_levels; ++l) {
         LSE_REQUIRE(desc->offsets[l + 1] > desc->offsets[l], "%s: level %d is empty", who, l);
@@ -596,9 +608,22 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
 extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                             float *dtable, float *dx, int64_t n, lse_stream_t stream)
 {
+    return lse_hash_bwd_levels(desc, x01, dy, table, dtable, dx, 0, 0, desc ? desc->n_levels : 0, n, stream);
+}
+
+extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
+                                   float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin,
+                                   int32_t level_end, int64_t n, lse_stream_t stream)
+{
     GridParams g;
     int rc = fill_params(desc, g, "lse_hash_bwd");
     if (rc) return rc;
+    LSE_REQUIRE(0 <= level_begin && level_begin <= level_end && level_end <= g.n_levels,
+                "lse_hash_bwd_levels: bad level range [%d, %d)", level_begin, level_end);
+    g.l_begin = level_begin;
+    g.l_end = level_end;
+    g.dx_accumulate = dx_accumulate;
+    if (level_begin == level_end && !(dx && !dx_accumulate)) return LSE_OK;
     LSE_REQUIRE(n >= 0, "lse_hash_bwd: n < 0");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(x01 && dy && dtable, "lse_hash_bwd: null pointer");

@@ -48,6 +48,58 @@ def allreduce_grads(flat_grad: torch.Tensor, async_op: bool = False):
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+class OverlappedGradExchange:
+    """The one all-reduce of the step, cut in two so that most of it hides behind the tail of the backward pass.
+
+    48.8 of the 48.9 MB of gradients belong to the hash table, and the hash backward is the LAST kernel of the backward
+    pass, so a plain all-reduce has nothing to overlap with.  With this object installed the hash backward runs in two
+    launches (ops.HASH_BWD_SPLIT): levels >= ``split_level`` first -- at the default split 8 x 4 MB of the table -- whose
+    slice of the flat gradient buffer is handed to an asynchronous all-reduce (RCCL runs it on its own stream) while the
+    second launch computes the remaining levels; ``finish()`` then reduces the rest and waits.  Results are identical to
+    ``allreduce_grads`` (same sum over ranks, element for element).  Requires optim.FlatParams (gradients accumulate in
+    place in one buffer)."""
+
+    def __init__(self, flat, table_param: torch.nn.Parameter, level_offsets, split_level: int):
+        idx = [i for i, p in enumerate(flat.params) if p is table_param]
+        assert idx, "table parameter is not part of the FlatParams"
+        base = flat.offsets[idx[0]]
+        self.flat = flat
+        self.split_level = int(split_level)
+        # table layout: level l occupies entries [offsets[l], offsets[l+1]) with 2 features each
+        self.lo = base + 2 * int(level_offsets[split_level])
+        self.hi = base + table_param.numel()
+        self._works = []
+
+    def install(self):
+        from . import ops
+        ops.HASH_BWD_SPLIT = (self.split_level, self._first_part_ready)
+
+    def uninstall(self):
+        from . import ops
+        ops.HASH_BWD_SPLIT = None
+
+    def _first_part_ready(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            self._works.append(dist.all_reduce(self.flat.grad[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Call after backward(): exchanges what the first part did not cover and waits for everything."""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            self._works.clear()
+            return
+        g = self.flat.grad
+        if not self._works:      # the split did not trigger (e.g. no hash backward ran): one plain all-reduce
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return
+        if self.lo > 0:
+            self._works.append(dist.all_reduce(g[:self.lo], op=dist.ReduceOp.SUM, async_op=True))
+        if self.hi < g.numel():
+            self._works.append(dist.all_reduce(g[self.hi:], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+
+
 def broadcast_params(flat_data: torch.Tensor, src: int = 0):
     """Initial parameter replication (DDP's constructor broadcast)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

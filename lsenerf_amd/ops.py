@@ -298,8 +298,18 @@ class _HashFn(torch.autograd.Function):
         dtable = direct if direct is not None else torch.zeros_like(table)
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
-        _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
-                  ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
+        split = HASH_BWD_SPLIT
+        if split is not None and direct is not None and 0 < split[0] < meta.n_levels:
+            # fine levels first (most of the table bytes); their gradients are final when the callback runs, so the caller
+            # can start exchanging them while the coarse levels are still being computed (dist.OverlappedGradExchange)
+            for lo, hi, acc in ((split[0], meta.n_levels, 0), (0, split[0], 1)):
+                _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                          ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), acc, lo, hi, n, _stream())
+                if acc == 0:
+                    split[1]()
+        else:
+            _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                      ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
         return dx, (None if direct is not None else dtable), None
 
 
@@ -383,6 +393,7 @@ class _MlpFn(torch.autograd.Function):
         return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None
 
 
+HASH_BWD_SPLIT = None        # (level, callback) installed by dist.OverlappedGradExchange: two launches, callback in between
 DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated leaf .grad (see _direct_grad)
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)

@@ -84,3 +84,57 @@ def test_shard_rays_partition():
     parts = [shard_rays(32768, r, 8) for r in range(8)]
     assert parts[0] == slice(0, 4096) and parts[7] == slice(28672, 32768)
     assert sum(p.stop - p.start for p in parts) == 32768
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist, ops
+    from lsenerf_amd.optim import FlatParams
+    ldist.init_from_env("gloo")
+    torch.manual_seed(0)
+    other = torch.nn.Parameter(torch.randn(100))
+    table = torch.nn.Parameter(torch.randn(2 * 96))         # 3 "levels" of 32 entries x 2 features
+    tail = torch.nn.Parameter(torch.randn(7))
+    flat = FlatParams([other, table, tail])
+    ex = ldist.OverlappedGradExchange(flat, table, level_offsets=(0, 32, 64, 96), split_level=1)
+    ex.install()
+    assert ops.HASH_BWD_SPLIT[0] == 1
+    res = []
+    for use_split in (True, False):
+        flat.zero_grad()
+        g = torch.Generator().manual_seed(10 + rank)
+        # what the two hash-backward launches do: levels >= split first, callback, then the rest; other grads arrive around it
+        other.grad.add_(torch.randn(100, generator=g))
+        table.grad[64:].add_(torch.randn(128, generator=g))
+        if use_split:
+            ops.HASH_BWD_SPLIT[1]()
+        table.grad[:64].add_(torch.randn(64, generator=g))
+        tail.grad.add_(torch.randn(7, generator=g))
+        ex.finish()           # without the callback: falls back to one plain all-reduce
+        res.append(flat.grad.clone())
+    ex.uninstall()
+    assert ops.HASH_BWD_SPLIT is None
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_equals_plain_allreduce(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    split, plain = torch.load(out)
+    assert torch.equal(split, plain)
+    # and both are the sum over the two ranks' gradients
+    exp = torch.zeros_like(plain)
+    offs = (0, 128, 128 + 192)     # FlatParams aligns every parameter to 64 floats
+    for rank in range(2):
+        g = torch.Generator().manual_seed(10 + rank)
+        exp[offs[0]:offs[0] + 100] += torch.randn(100, generator=g)
+        hi = torch.randn(128, generator=g)
+        lo = torch.randn(64, generator=g)
+        exp[offs[1]:offs[1] + 64] += lo
+        exp[offs[1] + 64:offs[1] + 192] += hi
+        exp[offs[2]:offs[2] + 7] += torch.randn(7, generator=g)
+    assert torch.allclose(plain, exp)

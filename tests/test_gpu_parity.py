@@ -172,6 +172,32 @@ def test_hash_fwd_bwd(L, T):
     assert nmax_err(xg.grad[8:], xc.grad[8:]) < TOL_GRAD
 
 
+def test_hash_bwd_level_ranges_add_up():
+    """lse_hash_bwd_levels: two launches over disjoint level ranges (the second accumulating d(x)) == one full launch."""
+    import ctypes
+    from lsenerf_amd import _lib
+    ops = _ops()
+    meta = ops.make_grid_meta()
+    g = torch.Generator().manual_seed(5)
+    N = 3000
+    t = torch.linspace(0, 1, N)[:, None]
+    x = (0.1 + 0.8 * t * torch.tensor([[0.9, 0.5, 0.3]]) + 0.01 * torch.rand(N, 3, generator=g)).clamp(0, 1).cuda()   # ray-like
+    table = ((torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.1).cuda()
+    dy = torch.randn(meta.n_levels, N, 2, generator=g).cuda()
+    desc = meta.desc()
+    P = lambda t_: ctypes.c_void_p(t_.data_ptr())
+    full_t, full_x = torch.zeros_like(table), torch.empty_like(x)
+    _lib.call("lse_hash_bwd", ctypes.byref(desc), P(x), P(dy), P(table), P(full_t), P(full_x), N, ops._stream())
+    part_t, part_x = torch.zeros_like(table), torch.full_like(x, 7.0)     # first launch overwrites d(x)
+    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 6, 16, N, ops._stream())
+    lo = 2 * meta.offsets[6]
+    assert float(part_t[:lo].abs().max()) == 0.0 and float(part_t[lo:].abs().max()) > 0
+    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 1, 0, 6, N, ops._stream())
+    assert nmax_err(part_t, full_t) < TOL_GRAD and nmax_err(part_x, full_x) < TOL_GRAD
+    with pytest.raises(_lib.LseHipError):
+        _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 9, 3, N, ops._stream())
+
+
 def test_hash_partition_of_unity_and_linearity_full_size():
     """Size-independent properties at the metric size (N = 4096 x 1024 would take 0.5 GB of features; 2^20 here and the
     bench covers the full N): a constant table encodes to that constant; the encoding is linear in the table."""
