@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void volrend_bwd_kernel(const float *__restric
             d_sigma[i] = dsd * dt;
             if (d_rgb) {
                 float *dc = d_rgb + i * rgb_stride;
-                dc[0] = w * gr; dc[1] = w * gg; dc[2] = w * gb;
+                if (rgb_stride == 4) *reinterpret_cast<float4 *>(dc) = make_float4(w * gr, w * gg, w * gb, 0.f);   // pad column too
+                else { dc[0] = w * gr; dc[1] = w * gg; dc[2] = w * gb; }
             }
         }
         carry_w += __shfl(incl_w, 0, 64);

@@ -536,9 +536,13 @@ class _VolRendFn(torch.autograd.Function):
     def backward(ctx, g_rgb, g_acc, g_dep, _g_w):
         t_starts, t_ends, sigmas, rgb, packed_info, weights = ctx.saved_tensors
         R = packed_info.shape[0]
-        d_sigma = torch.zeros_like(sigmas)
-        d_rgb = torch.zeros_like(rgb) if (rgb is not None and ctx.needs_input_grad[3]) else None
+        # every packed sample belongs to exactly one ray, so the kernel writes all of d_sigma; with the compact [N, 4] colour
+        # layout it also writes the pad column (one 16-B store per sample), so neither buffer needs a zero-fill
+        d_sigma = torch.empty_like(sigmas)
         stride = rgb.stride(0) if rgb is not None else 0
+        d_rgb = None
+        if rgb is not None and ctx.needs_input_grad[3]:
+            d_rgb = torch.empty_like(rgb) if (stride == 4 and rgb.is_contiguous() and rgb.data_ptr() % 16 == 0) else torch.zeros_like(rgb)
         _lib.call("lse_volrend_bwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
                   _rgb_ptr(rgb), stride, _chk(packed_info, torch.int64, "packed_info"), R, _f32(weights, "weights"),
                   _f32(_c(g_rgb), "g_rgb", True) if g_rgb is not None else None,
