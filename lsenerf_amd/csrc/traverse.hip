@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
         }
     }
 
-    int64_t n_samples = 0;
+    uint32_t n_samples = 0;   // per ray; the host bounds it far below 2^31 (budget: 2^24 loop iterations)
     // hang guard: with absurd inputs (t ~ 1e10 and a tiny step) `t_last += dt` stops making progress and the
     // published loops never end; every loop below draws from this budget (never reached for sane inputs).
     int budget = 1 << 24;
@@ -131,6 +131,10 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
     constexpr bool WRITE = MODE != 0;
     if (MODE == 1) base = a.chunk_starts[tid];
     if (MODE == 2) base = (int64_t)tid * a.cap;
+    // per-ray output cursors and a 32-bit capacity: keeps 64-bit address arithmetic out of the marching loop
+    int32_t *const out_ri = WRITE ? a.ray_indices + base : nullptr;
+    float *const out_ts = WRITE ? a.t_starts + base : nullptr, *const out_te = WRITE ? a.t_ends + base : nullptr;
+    const uint32_t cap32 = MODE == 2 ? (uint32_t)(a.cap < 0x7fffffff ? a.cap : 0x7fffffff) : 0xffffffffu;
     float t_last = ray_tmin;
     bool continuous = false;
     const int res[3] = {a.rx, a.ry, a.rz};
@@ -219,17 +223,14 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             const bool my_occ = (lane < nb) ? (a.binaries[s_cell[lane]] != 0) : false;
             const uint32_t occ_mask = (uint32_t)__ballot(my_occ);
 
-            // Flat marching loop: every iteration is either one marching step or one cell advance, chosen with
-            // selects instead of nested divergent loops (one backward branch per iteration).  It performs exactly the
-            // comparisons and additions of the published nested loops, in the same order.
             if (a.step_size <= 0.0f) {
                 for (int b = 0; b < nb; ++b) {   // one interval per occupied cell
                     const float t_traverse = s_tt[b];
                     if ((occ_mask >> b) & 1u) {
-                        if (WRITE && lane == 0 && (MODE == 1 || n_samples < a.cap)) {
-                            if (MODE == 1) a.ray_indices[base + n_samples] = tid;
-                            a.t_starts[base + n_samples] = t_last;
-                            a.t_ends[base + n_samples] = t_traverse;
+                        if (WRITE && lane == 0 && n_samples < cap32) {
+                            if (MODE == 1) out_ri[n_samples] = tid;
+                            out_ts[n_samples] = t_last;
+                            out_te[n_samples] = t_traverse;
                         }
                         n_samples++;
                         continuous = true;
@@ -239,40 +240,44 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                     t_last = t_traverse;
                 }
             } else {
-                int b = 0;
-                float t_traverse = s_tt[0];
-                while (b < nb && budget > 0) {
-                    --budget;
-                    const bool occ = (occ_mask >> b) & 1u;
-                    const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
-                    const bool reached = t_last + dt * 0.5f >= t_traverse;
-                    bool cell_done = reached;
-                    if (!reached) {
-                        const float t_next = t_last + dt;
-                        if (occ) {
-                            if (WRITE && lane == 0 && (MODE == 1 || n_samples < a.cap)) {
-                                if (MODE == 1) a.ray_indices[base + n_samples] = tid;
-                                a.t_starts[base + n_samples] = t_last;
-                                a.t_ends[base + n_samples] = t_next;
+                // One ray per wave: every branch below is wave-uniform (scalar), so the published nested loops are used as
+                // they are -- a tight marching loop per cell (add, compare, two stores, add, compare) instead of a flat
+                // one-event-per-iteration loop full of selects; the kernel is bound by instruction issue (4 waves share a
+                // SIMD, one lane of 64 does the arithmetic).  Same comparisons and additions in the same order.
+                for (int b = 0; b < nb && budget > 0; ++b) {
+                    const float t_traverse = s_tt[b];
+                    if ((occ_mask >> b) & 1u) {
+                        while (budget > 0) {
+                            --budget;
+                            const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
+                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            const float t_next = t_last + dt;
+                            if (WRITE && lane == 0 && n_samples < cap32) {
+                                if (MODE == 1) out_ri[n_samples] = tid;
+                                out_ts[n_samples] = t_last;
+                                out_te[n_samples] = t_next;
                             }
                             n_samples++;
                             continuous = true;
-                            cell_done = t_next >= t_traverse;
+                            t_last = t_next;
+                            if (t_next >= t_traverse) break;
                         }
-                        t_last = t_next;
-                    }
-                    if (cell_done) {
-                        if (!occ) continuous = false;
-                        ++b;
-                        if (b < nb) t_traverse = s_tt[b];
+                    } else {
+                        while (budget > 0) {
+                            --budget;
+                            const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
+                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            t_last = t_last + dt;
+                        }
+                        continuous = false;
                     }
                 }
             }
             __syncthreads();   // the next batch overwrites the LDS slots
         }
     }
-    if (MODE != 1 && lane == 0) a.chunk_cnts[tid] = n_samples;
-    if (MODE == 2 && lane == 0 && n_samples > a.cap) atomicOr(a.overflow, 1);
+    if (MODE != 1 && lane == 0) a.chunk_cnts[tid] = (int64_t)n_samples;
+    if (MODE == 2 && lane == 0 && n_samples > cap32) atomicOr(a.overflow, 1);
 }
 
 // single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
