@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblse_hip.so")
+LIB_PATH = os.environ.get("LSE_HIP_LIB", os.path.join(_HERE, "liblse_hip.so"))   # override: A/B builds of the same ABI
 
 LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
