@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 OUT=gpurun_out/pmc_mlp; mkdir -p $OUT
-export LSE_MLP_FWD_CFG=44 LSE_MLP_BWD_CFG=44
+
 rocprofv3 -L > $OUT/counters.txt 2>&1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"; do
   tag=$(echo $set | cut -d' ' -f1)
@@ -15,7 +15,7 @@ for f in glob.glob('gpurun_out/pmc_mlp/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'mlp_' in k or 'hash_' in k:
-            name = k.split('(')[0].replace('void (anonymous namespace)::','').replace('(anonymous namespace)::','')[:44]
+            name = k.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60]
             agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k)
