@@ -80,7 +80,7 @@ class GradPipeline:
             self.work, self.pending = None, False
 
 
-def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None):
+def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None, sharded=None):
     from lsenerf_amd import dist as ldist
     rb.origins.grad = None
     rb.directions.grad = None
@@ -97,6 +97,11 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
     loss.backward()
     if pipeline is not None:
         pipeline.start()
+        return ri.shape[0], loss
+    if sharded is not None:        # reduce-scatter -> Adam on this rank's 1/W shard -> all-gather
+        sharded.lr = opt.current_lr()
+        opt.step_count += 1
+        sharded.step()
         return ri.shape[0], loss
     if exchange is not None:
         exchange.finish()          # the fine levels' table gradients have been in flight since the middle of the hash backward
@@ -168,8 +173,11 @@ def main():
     # N > 1: the gradient all-reduce of step k is hidden behind the ray marcher of step k+1 (GradPipeline).
     # LSE_BENCH_EXCHANGE=plain selects the single blocking all-reduce; =overlap / =split the two-launch hash backward of
     # dist.OverlappedGradExchange (measured at N = 1: the second launch costs 0.28 ms, more than the exchange it hides).
-    exchange, pipeline = None, None
+    # =sharded: dist.ShardedAdamExchange (reduce-scatter, Adam on 1/W of the buffer, all-gather).
+    exchange, pipeline, sharded = None, None, None
     mode = os.environ.get("LSE_BENCH_EXCHANGE", "pipelined" if world > 1 else "plain")
+    if mode == "sharded":
+        sharded = ldist.ShardedAdamExchange(flat, lr=1e-2, eps=1e-15)
     if mode == "pipelined":
         pipeline = GradPipeline(opt, world)
     if mode in ("overlap", "split"):
@@ -179,7 +187,7 @@ def main():
 
     n_samples = 0
     for _ in range(args.warmup):
-        n_samples, _ = train_step(model, rb, target, jitter, opt, world, exchange, pipeline)
+        n_samples, _ = train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded)
     if pipeline is not None:
         pipeline.flush()
 
@@ -192,7 +200,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_samples, loss = train_step(model, rb, target, jitter, opt, world, exchange, pipeline)
+        n_samples, loss = train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded)
     if pipeline is not None:
         pipeline.flush()           # the K-th all-reduce + Adam belong to the timed K steps
     torch.cuda.synchronize()

@@ -138,3 +138,51 @@ def test_overlapped_exchange_equals_plain_allreduce(tmp_path):
         exp[offs[1] + 64:offs[1] + 192] += hi
         exp[offs[2]:offs[2] + 7] += torch.randn(7, generator=g)
     assert torch.allclose(plain, exp)
+
+
+def _adam_fn_cpu(p, g, m, v, lr, b1, b2, eps, step, scale):
+    g = g * scale
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m, (v.sqrt() / (1 - b2 ** step) ** 0.5).add_(eps), value=-lr / (1 - b1 ** step))
+
+
+def _sharded_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    ldist.init_from_env("gloo")
+    model = _model()
+    flat = FlatParams(model.parameters())
+    ldist.broadcast_params(flat.data)
+    ex = ldist.ShardedAdamExchange(flat, lr=1e-2, adam_fn=_adam_fn_cpu)
+    assert ex.per % 64 == 0 and ex.padded >= flat.data.numel() and ex.exp_avg.numel() == ex.per
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+    sl = ldist.shard_rays(64, rank, world)
+    for _ in range(3):
+        flat.zero_grad()
+        ((model(x[sl]) - y[sl]) ** 2).mean().backward()
+        ex.step()
+    torch.save(flat.data.clone(), out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adam_equals_full_batch_and_replicates(tmp_path):
+    out = str(tmp_path / "p")
+    mp.spawn(_sharded_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    p0, p1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(p0, p1)                        # identical parameters on every rank
+    from lsenerf_amd.optim import FlatParams
+    model = _model()
+    flat = FlatParams(model.parameters())
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+    state = {"m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)}
+    for step in range(1, 4):
+        flat.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        _adam_cpu(flat, state, 1e-2, 1.0, step)
+    assert torch.allclose(p0, flat.data, atol=1e-6)
