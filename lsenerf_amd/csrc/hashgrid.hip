@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg)
+                                                              int64_t n, int dbg, int few_runs)
 {
     constexpr int kRounds = 1;                 // one 64-sample round per wave
     constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
@@ -456,7 +456,38 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
             // is written for few instructions: one probe per corner, no retry rounds (a lost slot goes straight to memory),
             // every DS operation issued by all lanes (idle lanes aim at a private dummy word) so that a batch of 8 goes out
             // back to back with one wait.
-            {
+            const uint64_t ends_mask = __builtin_amdgcn_ballot_w64(run_end && !(dbg & 2));
+            const int n_ends = __builtin_popcountll(ends_mask);
+            if (n_ends <= few_runs) {
+                // Coarse levels: a wave ends only a handful of runs, and almost all of the ~500 instructions of the cache
+                // path below would be spent on idle lanes.  Instead the run ends park their 8 indices + 16 sums in LDS
+                // (the zeroed payload area doubles as staging) and the wave re-reads them with 16 lanes per run -- lane =
+                // (corner, feature), 4 runs per instruction -- and adds straight to memory: the two features and the
+                // x / x+1 neighbours of an entry share requests inside the instruction.
+                if (n_ends > 0) {
+                    lds_u32 *stage = (lds_u32 *)val;           // [run][8 idx | 16 values]
+                    if (run_end && !(dbg & 2)) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0));
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) stage[rank * 24 + c] = idx[c];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) stage[rank * 24 + 8 + k] = __float_as_uint(v[k]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int k16 = lane & 15;
+                    for (int r0 = lane >> 4; r0 < n_ends; r0 += 4) {
+                        const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
+                        const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
+                        if (a != 0.f) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int s_ = lane; s_ < n_ends * 24; s_ += 64) stage[s_] = 0u;   // the payload area must read zero again
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
                 const bool act = run_end && !(dbg & 2);
                 uint32_t used = 0;   // occupied cache slots (wave-uniform)
                 if (__builtin_amdgcn_ballot_w64(act) != 0) {
@@ -640,6 +671,7 @@ extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, 
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
     static const int dbg = getenv("LSE_HASH_BWD_DBG") ? atoi(getenv("LSE_HASH_BWD_DBG")) : 0;   // timing experiments only
     if (impl == 1 && lines_ok) {
+        static const int few_runs = getenv("LSE_HASH_BWD_FEW") ? atoi(getenv("LSE_HASH_BWD_FEW")) : 6;   // tuned on MI355X: 4..8 equal, 16 already slower
         static const int gran = getenv("LSE_HASH_BWD_GRAN") ? atoi(getenv("LSE_HASH_BWD_GRAN")) : 2;
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
@@ -647,7 +679,7 @@ extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, 
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
 #define LSE_LAUNCH_CACHED(DX, SLOTS, ENTLOG2)                                                                          \
     hipLaunchKernelGGL((hash_bwd_cached_kernel<DX, SLOTS, ENTLOG2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2, \
-                       tb2, dtable, dx, n, dbg)
+                       tb2, dtable, dx, n, dbg, few_runs)
         if (gran == 2) {   // 512 slots of one 32-B sector
             if (dx) LSE_LAUNCH_CACHED(true, 512, 2);
             else LSE_LAUNCH_CACHED(false, 512, 2);

@@ -51,6 +51,13 @@ def main():
         print(f"hash_bwd(dx) median {med:.3f} ms  min {mn:.3f} ms  -> {1024*N/med/1e6:.0f} GB/s algorithmic", flush=True)
         med, mn = timeit(lambda: bwd(False))
         print(f"hash_bwd(no dx) median {med:.3f} ms  min {mn:.3f}", flush=True)
+        for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 16)):
+            def rng():
+                _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), ctypes.c_void_p(x01.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
+                          ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(dtab.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
+                          0, lo, hi, N, ops._stream())
+            med, mn = timeit(rng)
+            print(f"hash_bwd levels [{lo},{hi}) median {med:.3f} ms", flush=True)
     if want("mlp"):
         from lsenerf_amd import _lib as L
         for name, meta, xin in (("head", ops.MlpMeta(16, 64, 2, L.LSE_ACT_SIGMOID, L.LSE_IN_ROWMAJOR), torch.randn(N, 16, device=dev)),
