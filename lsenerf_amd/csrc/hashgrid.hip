@@ -320,7 +320,12 @@ __device__ __forceinline__ int row_shr_i32(int v)
 // lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2])
 __device__ __forceinline__ int quad_swap1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
 
-// One step of the flag-based segmented inclusive scan inside the 16-lane rows (pure VALU: DPP operand + fma).
+// acc += (value of acc in the lane OFF below, same 16-lane row; 0 outside the row) * mul -- one fused DPP instruction
+// (the compiler emits v_mov_b32_dpp + v_fma for the builtin form).  The s_nop covers the "VALU write -> DPP read" wait
+// states for the first value of a step; the 16 values of a step are independent of each other.
+#define LSE_FMAC_DPP(acc, mul, CTRL) asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL : "+v"(acc) : "v"(mul))
+
+// One step of the flag-based segmented inclusive scan inside the 16-lane rows.
 // Returns false (wave-uniform) when no lane needs this or any later step.
 template <int OFF>
 __device__ __forceinline__ bool seg_scan_row_step(float (&v)[16], int &flag, int row_pos)
@@ -329,10 +334,34 @@ __device__ __forceinline__ bool seg_scan_row_step(float (&v)[16], int &flag, int
     if (__builtin_amdgcn_ballot_w64(need) == 0) return false;
     const float nf = need ? 1.f : 0.f;
     const int fo = row_shr_i32<OFF>(flag);
+    asm volatile("s_nop 1");
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = fmaf(row_shr_f32<OFF>(v[k]), nf, v[k]);
+    for (int k = 0; k < 16; ++k) {
+        if (OFF == 1) LSE_FMAC_DPP(v[k], nf, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        if (OFF == 2) LSE_FMAC_DPP(v[k], nf, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        if (OFF == 4) LSE_FMAC_DPP(v[k], nf, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        if (OFF == 8) LSE_FMAC_DPP(v[k], nf, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    }
     flag |= need ? fo : 0;
     return true;
+}
+
+// Carry of the row-local scans across the three row borders: rows 1 and 3 take the last lane of rows 0 and 2
+// (row_bcast:15), then rows 2 and 3 take lane 31 (row_bcast:31), each lane only while its run reaches back that far.
+// open = "no run head between my row's first lane and me".
+__device__ __forceinline__ void seg_scan_cross_rows(float (&v)[16], int open, int lane)
+{
+    const int row = lane >> 4;
+    if (__builtin_amdgcn_ballot_w64(open && row != 0) == 0) return;
+    const float fa = (open && (row & 1)) ? 1.f : 0.f;
+    int open47 = open;       // rows 1, 3 receive open(lane 15), open(lane 47)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(open47));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) LSE_FMAC_DPP(v[k], fa, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    const float fb = (row == 2 ? open : (row == 3 ? (open && open47) : 0)) ? 1.f : 0.f;
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int k = 0; k < 16; ++k) LSE_FMAC_DPP(v[k], fb, "row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
 
 template <bool WITH_DX, int kSlots, int kEntLog2>
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg, int few_runs)
+                                                              int64_t n, int dbg, int few_runs, int second_probe)
 {
     constexpr int kRounds = 1;                 // one 64-sample round per wave
     constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
@@ -430,16 +459,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                                 : (off == 4) ? row_shr_i32<4>(open) : row_shr_i32<8>(open);
                     open &= (row_pos >= off) ? o : 1;
                 }
-#pragma unroll
-                for (int R = 1; R < 4; ++R) {
-                    const bool m = (lane >> 4) == R && open;
-                    if (__builtin_amdgcn_ballot_w64(m) != 0) {
-                        const float mf = m ? 1.f : 0.f;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k)
-                            v[k] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 16 * R - 1)), mf, v[k]);
-                    }
-                }
+                seg_scan_cross_rows(v, open, lane);
             }
             if (WITH_DX) {
 #pragma unroll
@@ -502,7 +522,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                     // float LDS atomics run at ~3 cycles per LANE on gfx950 (tools/micro/lds_ops.hip: ds_add_f32 194 cycles
                     // per instruction, ds_cmpst_b64 22): add both features with one 64-bit compare-and-swap
                     lds_u64 *va[8];
-                    bool to_mem[8];
+                    bool to_mem[8], okc[8];
                     uint64_t cur[8], prev[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -514,10 +534,41 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
                                     (uint16_t)slot[c];
                             used += __builtin_popcountll(cm);
                         }
-                        const bool ok = claim || (act && old[c] == (idx[c] >> kEntLog2));
-                        to_mem[c] = act && !ok;
-                        va[c] = ok ? (lds_u64 *)&val[slot[c] * kPay + (idx[c] & (kEnt - 1)) * 2] : dummy64;
+                        okc[c] = claim || (act && old[c] == (idx[c] >> kEntLog2));
+                        to_mem[c] = act && !okc[c];
                     }
+                    if (second_probe) {
+                        // second chance in the neighbouring slot for the corners that lost their first one (batched the same way)
+                        bool any = false;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) any = any || to_mem[c];
+                        if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                            uint32_t old2[8];
+#pragma unroll
+                            for (int c = 0; c < 8; ++c)
+                                old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + 1) & (kSlots - 1)] : dummy32, kNoLine,
+                                                  to_mem[c] ? (idx[c] >> kEntLog2) : kNoLine);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                const bool claim = to_mem[c] && old2[c] == kNoLine;
+                                const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                                if (cm) {
+                                    if (claim)
+                                        list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                            (uint16_t)((slot[c] + 1) & (kSlots - 1));
+                                    used += __builtin_popcountll(cm);
+                                }
+                                if (claim || (to_mem[c] && old2[c] == (idx[c] >> kEntLog2))) {
+                                    slot[c] = (slot[c] + 1) & (kSlots - 1);
+                                    okc[c] = true;
+                                    to_mem[c] = false;
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        va[c] = okc[c] ? (lds_u64 *)&val[slot[c] * kPay + (idx[c] & (kEnt - 1)) * 2] : dummy64;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) cur[c] = *va[c];
 #pragma unroll
@@ -672,6 +723,7 @@ extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, 
     static const int dbg = getenv("LSE_HASH_BWD_DBG") ? atoi(getenv("LSE_HASH_BWD_DBG")) : 0;   // timing experiments only
     if (impl == 1 && lines_ok) {
         static const int few_runs = getenv("LSE_HASH_BWD_FEW") ? atoi(getenv("LSE_HASH_BWD_FEW")) : 6;   // tuned on MI355X: 4..8 equal, 16 already slower
+        static const int second_probe = getenv("LSE_HASH_BWD_PROBE2") ? atoi(getenv("LSE_HASH_BWD_PROBE2")) : 0;
         static const int gran = getenv("LSE_HASH_BWD_GRAN") ? atoi(getenv("LSE_HASH_BWD_GRAN")) : 2;
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
@@ -679,7 +731,7 @@ extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, 
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
 #define LSE_LAUNCH_CACHED(DX, SLOTS, ENTLOG2)                                                                          \
     hipLaunchKernelGGL((hash_bwd_cached_kernel<DX, SLOTS, ENTLOG2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2, \
-                       tb2, dtable, dx, n, dbg, few_runs)
+                       tb2, dtable, dx, n, dbg, few_runs, second_probe)
         if (gran == 2) {   // 512 slots of one 32-B sector
             if (dx) LSE_LAUNCH_CACHED(true, 512, 2);
             else LSE_LAUNCH_CACHED(false, 512, 2);
