@@ -270,14 +270,18 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(GridParams g, const float
 //     compare-and-swap adds both features (ds_add_f32 runs at ~3 cycles per LANE on gfx950, tools/micro/lds_ops.hip);
 //     a corner whose slot belongs to another sector goes straight to memory, so the cache is purely an optimisation;
 //   * after each level the occupied slots (kept in a list) are flushed with one 8-lane x 32-B atomic per sector.
+//   * a wave that ends at most `few_runs` (6) runs at a level -- the coarse levels -- skips the cache: the run ends park
+//     their 8 indices + 16 sums in LDS and the wave adds them to memory with 16 lanes per run (lane = corner x feature),
+//     because the ~500 instructions of the cache path would be spent on idle lanes (levels 0-3: 0.66 -> 0.37 ms).
 //   The memory-side atomic units are priced per 32-B sector request at ~20 G/s (rocprof WRITE_SIZE / 32 B tracks the
 //   kernel time).  tools/sim_hash_bwd_requests.py models the policy: 256 slots of a 64-B line flush 9.1 sectors per
-//   sample and send 4.2 corner updates straight to memory (two 4-B atomics each; measured 16.5 sector writes per
-//   sample, 3.54 ms); 512 sector-sized slots in the same 16 KB collide less: 9.8 + 2.6 (3.23 ms).  The kernel above
-//   writes 21 per sample (4.37 ms).  Tried and dropped: more probe rounds (each costs more issue slots than its saved
-//   requests -- the kernel is close to issue-bound as well: VALU+SALU+LDS issue ~ 75 % of the SIMD cycles at the
-//   2 waves/SIMD that 79 KB of LDS allow), two half-wave phases per fine level, ds_add_f32 payload adds, a slot function
-//   linear in the cell coordinates.
+//   sample and send 4.2 corner updates straight to memory (3.54 ms); 512 sector-sized slots in the same 16 KB collide
+//   less: 9.8 + 2.6 (measured 12.3 sector writes per sample, 3.23 ms); writing a collision's two features through a lane
+//   pair in one instruction instead of two: 3.05 ms; the few-runs path: 2.91 ms.  The kernel above writes 21 sectors per
+//   sample (4.37 ms).  It now sits at the atomic rate for its ~13 requests per sample (2.7 ms); the issue slots
+//   (VALU+SALU+LDS ~ 75 % of the SIMD cycles before the last two steps, at the 2 waves/SIMD that 79 KB of LDS allow) are
+//   the second bound.  Tried and dropped: more probe rounds (second_probe: neutral), two half-wave phases per fine
+//   level, ds_add_f32 payload adds, a slot function linear in the cell coordinates, one probe per x-row.
 constexpr uint32_t kNoLine = 0xFFFFFFFFu;
 
 // LDS pointers carry their address space so that every cache access is a ds_* instruction (generic pointers make the
