@@ -35,6 +35,7 @@ struct TraverseArgs {
     float *t_starts, *t_ends;
     int64_t cap;          // MODE 2: samples of ray r go to slots [r*cap, (r+1)*cap)
     int32_t *overflow;    // MODE 2: set when a ray produced more than cap samples (never, by the host's bound)
+    int vec_march;        // constant step: march 64 steps of a cell at once (march_cell_vec); 0 = published serial loop only
 };
 
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
@@ -73,6 +74,63 @@ __device__ bool slab(const float o[3], const float inv[3], const float *__restri
     tmin = fmaxf(tmin, near_p);
     tmax = fminf(tmax, far_p);
     return true;
+}
+
+// Constant step (cone_angle == 0): inside one binade the serial recurrence t <- fl(t + dt) is an exact arithmetic
+// progression of the float's BIT PATTERN: every t is a multiple of the binade's ulp u, dt = q*u + r, and round-to-nearest
+// turns t + dt into t + q*u or t + (q+1)*u depending on r alone -- unless r is exactly u/2 (a tie, which rounds to even and
+// therefore depends on t).  So with dm = bits(fl(t0 + dt)) - bits(t0), the k-th value of the recurrence is
+// bits(t0) + k*dm, bit for bit, as long as the exponent does not change and the sum is not a tie.  That lets all 64 lanes
+// evaluate 64 consecutive marching steps of a cell at once (lane k: t_k, the published `reached` test on t_k and the
+// `cell done` test on t_{k+1}, each with the same float operations the serial loop performs), find the first step that
+// stops with a ballot, and store up to 64 samples with one instruction.  Any failed precondition (tie, binade border
+// within 65 steps, no progress, tiny or non-positive t, nearly exhausted iteration budget) returns false and the caller
+// runs the published serial loop for that cell.  Returns true when the cell is finished.
+template <int MODE>
+__device__ __forceinline__ bool march_cell_vec(bool occupied, float t_traverse, float dt, float &t_last, uint32_t &n_samples,
+                                               bool &continuous, int &budget, int lane, int tid, int32_t *out_ri,
+                                               float *out_ts, float *out_te, uint32_t cap32)
+{
+    constexpr bool WRITE = MODE != 0;
+    const float half = dt * 0.5f;
+    while (true) {
+        const int t0b = __float_as_int(t_last);
+        const float t1 = t_last + dt;
+        const int dm = __float_as_int(t1) - t0b;
+        const float inc = t1 - t_last;                                          // exact (same binade)
+        const float r = dt - inc;                                               // exact (Sterbenz)
+        const float ulp = __int_as_float(t0b & 0x7f800000) * 1.1920928955078125e-07f;   // 2^(e-23)
+        const bool ok = budget > 256 && t_last >= 1e-20f && dm > 0 && dm < (1 << 22) &&
+                        (((t0b + 65 * dm) ^ t0b) & 0xff800000) == 0 && fabsf(r) * 2.0f != ulp;
+        if (!ok) return false;
+        const float tk = __int_as_float(t0b + lane * dm), tn = __int_as_float(t0b + (lane + 1) * dm);
+        const bool reached = tk + half >= t_traverse;
+        const uint64_t m_reached = __builtin_amdgcn_ballot_w64(reached);
+        budget -= 64;
+        if (!occupied) {
+            if (m_reached == 0) {
+                t_last = __int_as_float(t0b + 64 * dm);
+                continue;
+            }
+            t_last = __int_as_float(t0b + __builtin_ctzll(m_reached) * dm);
+            return true;
+        }
+        const uint64_t m_stop = m_reached | __builtin_amdgcn_ballot_w64(tn >= t_traverse);
+        int count = 64;
+        if (m_stop != 0) {
+            const int K = __builtin_ctzll(m_stop);
+            count = ((m_reached >> K) & 1) ? K : K + 1;                           // `reached` stops before emitting sample K
+        }
+        if (WRITE && lane < count && n_samples + (uint32_t)lane < cap32) {
+            if (MODE == 1) out_ri[n_samples + lane] = tid;
+            out_ts[n_samples + lane] = tk;
+            out_te[n_samples + lane] = tn;
+        }
+        n_samples += (uint32_t)count;
+        if (count > 0) continuous = true;
+        t_last = __int_as_float(t0b + count * dm);
+        if (m_stop != 0) return true;
+    }
 }
 
 // MODE 0: count per ray; 1: write at chunk_starts (second pass of the published two-pass scheme);
@@ -246,7 +304,14 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 // SIMD, one lane of 64 does the arithmetic).  Same comparisons and additions in the same order.
                 for (int b = 0; b < nb && budget > 0; ++b) {
                     const float t_traverse = s_tt[b];
-                    if ((occ_mask >> b) & 1u) {
+                    const bool occupied = (occ_mask >> b) & 1u;
+                    if (CONST_DT && a.vec_march &&
+                        march_cell_vec<MODE>(occupied, t_traverse, a.step_size, t_last, n_samples, continuous, budget, lane, tid,
+                                             out_ri, out_ts, out_te, cap32)) {
+                        if (!occupied) continuous = false;
+                        continue;
+                    }
+                    if (occupied) {
                         while (budget > 0) {
                             --budget;
                             const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
@@ -325,6 +390,12 @@ __global__ __launch_bounds__(256) void compact_slots_kernel(const float *__restr
     }
 }
 
+static int vec_march_enabled()
+{
+    static const int v = getenv("LSE_TRAVERSE_VEC") ? atoi(getenv("LSE_TRAVERSE_VEC")) : 1;
+    return v;
+}
+
 }  // namespace
 
 extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
@@ -344,7 +415,7 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
     if (mode == 0) LSE_REQUIRE(chunk_cnts, "lse_traverse_grids: count pass needs chunk_cnts");
     if (mode == 1) LSE_REQUIRE(chunk_starts && ray_indices && t_starts && t_ends, "lse_traverse_grids: write pass needs outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr};
+                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr, vec_march_enabled()};
     const int blocks = n_rays;   // one wave per ray
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
@@ -373,7 +444,7 @@ extern "C" int lse_traverse_grids_slots(const float *rays_o, const float *rays_d
     LSE_REQUIRE((int64_t)levels * rx * ry * rz < (1ll << 31), "lse_traverse_grids_slots: grid too large (levels*cells >= 2^31)");
     LSE_REQUIRE(cap >= 1 && chunk_cnts && t_start_slots && t_end_slots && overflow, "lse_traverse_grids_slots: bad outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow};
+                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow, vec_march_enabled()};
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
     if (const_dt) hipLaunchKernelGGL((traverse_kernel<2, true>), dim3(n_rays), dim3(64), 0, st, a);

@@ -63,6 +63,36 @@ def test_traverse_single_pass_equals_two_pass(levels, res, cone, step):
             assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("step", [0.0034641, 2.0 ** -8, 2.0 ** -8 + 2.0 ** -21, 2.0 ** -7 + 2.0 ** -24, 0.01, 3e-4])
+def test_traverse_vector_march_is_bit_exact_across_binades_and_ties(step):
+    """Constant step: the 64-steps-at-once marcher (bit-pattern arithmetic progression per binade) must reproduce the
+    serial float recurrence exactly -- long rays crossing many binades (t from 0.03 to ~28), step sizes whose sum with t is
+    an exact rounding tie in some binades (2^-8 + 2^-21 at t in [8,16)), sparse and full grids, and the serial kernel
+    (LSE_TRAVERSE_VEC=0 semantics are covered by the C oracle: both must agree with it)."""
+    from oracle import sampling as osamp
+    ops = _ops()
+    R, levels, res = 96, 4, 32
+    g = torch.Generator().manual_seed(int(step * 1e7) % 1000)
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.2
+    d = torch.randn(R, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    d[:8] = torch.tensor([1.0, 0.0, 0.0])                        # axis-parallel rays: many samples per cell
+    aabbs = torch.stack([osamp.enlarge_aabb(torch.tensor([-2.0, -2, -2, 2, 2, 2]), 2 ** i) for i in range(levels)])
+    near = torch.full((R,), 0.03) + torch.rand(R, generator=g) * step
+    far = torch.full((R,), 1e3)
+    for frac in (1.0, 0.35):
+        b = random_binaries(levels, res, frac, seed=7) if frac < 1 else torch.ones(levels, res, res, res, dtype=torch.bool)
+        ri, ts, te, packed = osamp.traverse_grids(o, d, b, aabbs, near, far, float(step), 0.0)
+        args = (o.cuda(), d.cuda(), b.cuda().view(torch.uint8), aabbs.cuda(), near.cuda(), far.cuda(), float(step), 0.0)
+        for kw in ({}, {"max_span": float((aabbs[-1, 3:] - aabbs[-1, :3]).norm())}):
+            if kw and ri.numel() / R * 1.0 > 3e5:
+                continue
+            hri, hts, hte, hpacked = ops.traverse_grids(*args, **kw)
+            assert torch.equal(hpacked.cpu(), packed)
+            assert torch.equal(hts.cpu(), ts) and torch.equal(hte.cpu(), te) and torch.equal(hri.cpu().long(), ri)
+        assert float(ts.max()) > 16.0 and ri.numel() > 1000
+
+
 def test_traverse_edge_cases():
     from oracle import sampling as osamp
     ops = _ops()
