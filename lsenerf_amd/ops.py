@@ -341,6 +341,7 @@ class _MlpFn(torch.autograd.Function):
                   _chk(selector, torch.uint8, "selector", True), float(density_scale or 0.0), n, _stream())
         ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info, selector)
         ctx.meta, ctx.n, ctx.out_cols, ctx.density_scale = meta, n, out_cols, density_scale
+        ctx.set_materialize_grads(False)
         return out if sigma is None else (out, sigma)
 
     @staticmethod
@@ -528,6 +529,7 @@ class _VolRendFn(torch.autograd.Function):
                   ctypes.c_void_p(out_acc.data_ptr()), ctypes.c_void_p(out_dep.data_ptr()), _stream())
         ctx.save_for_backward(t_starts, t_ends, sigmas, rgb, packed_info, weights)
         ctx.mark_non_differentiable(weights)
+        ctx.set_materialize_grads(False)     # unused outputs (accumulation / depth) arrive as None, not as zero-filled tensors
         if out_rgb is None:
             out_rgb = torch.zeros((R, 3), dtype=torch.float32, device=dev)
         return out_rgb, out_acc, out_dep, weights
