@@ -93,6 +93,37 @@ def test_traverse_vector_march_is_bit_exact_across_binades_and_ties(step):
         assert float(ts.max()) > 16.0 and ri.numel() > 1000
 
 
+def test_traverse_full_size_properties():
+    """Metric size (4096 rays x 1024 samples, 4-level 128^3 grid, constant step): size-independent properties of the packed
+    output -- exact per-ray counts, contiguous intervals (t_end[i] == t_start[i+1] bit for bit inside a ray), every
+    interval exactly one float-add of the step long, ray-sorted indices -- and single pass == two-pass, vector == serial."""
+    import os
+    from oracle import sampling as osamp
+    ops = _ops()
+    R, S = 4096, 1024
+    g = torch.Generator().manual_seed(11)
+    o = (torch.rand(R, 3, generator=g) - 0.5).cuda()
+    d = torch.randn(R, 3, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).cuda()
+    step = 2 * 3 ** 0.5 / 1000
+    aabbs = torch.stack([osamp.enlarge_aabb(torch.tensor([-1.0, -1, -1, 1, 1, 1]), 2 ** i) for i in range(4)]).cuda()
+    b = torch.ones(4, 128, 128, 128, dtype=torch.uint8).cuda()
+    near = torch.full((R,), 0.05).cuda()
+    far = torch.full((R,), 0.05 + S * step - 0.25 * step).cuda()
+    diag = float((aabbs[-1, 3:] - aabbs[-1, :3]).norm())
+    one = ops.traverse_grids(o, d, b, aabbs, near, far, step, 0.0, max_span=min(diag, float(far[0] - near[0])))
+    two = ops.traverse_grids(o, d, b, aabbs, near, far, step, 0.0)
+    for a_, b_ in zip(one, two):
+        assert torch.equal(a_, b_)
+    ri, ts, te, packed = one
+    assert ri.numel() == R * S and bool((packed[:, 1] == S).all())
+    assert torch.equal(ri.view(R, S), torch.arange(R, device="cuda", dtype=torch.int32)[:, None].expand(R, S))
+    ts, te = ts.view(R, S), te.view(R, S)
+    assert torch.equal(te[:, :-1], ts[:, 1:])                                 # contiguous inside a ray
+    assert torch.equal(te, ts + torch.tensor(step, dtype=torch.float32, device="cuda"))   # one float add per step
+    assert torch.equal(ts[:, 0], near)
+
+
 def test_traverse_edge_cases():
     from oracle import sampling as osamp
     ops = _ops()
