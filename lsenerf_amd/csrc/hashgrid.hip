@@ -76,7 +76,10 @@ __device__ __forceinline__ void pos_fract(float x, float scale, float &w, uint32
 }
 
 constexpr int kFwdThreads = 256;
-constexpr int kFwdItems = 4;   // samples per lane -> 32 independent gathers in flight
+#ifndef LSE_FWD_ITEMS
+#define LSE_FWD_ITEMS 4
+#endif
+constexpr int kFwdItems = LSE_FWD_ITEMS;   // samples per lane -> 32 independent gathers in flight
 
 __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, const float *__restrict__ x,
                                                                const float2 *__restrict__ table,
