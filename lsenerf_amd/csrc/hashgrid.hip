@@ -8,9 +8,11 @@
 //   * lanes are consecutive samples.  Samples of one ray are consecutive, so at the coarse levels the 64
 //     lanes of a gather instruction fall into a handful of cells (same cache lines) and the hardware
 //     coalesces them; only the fine hashed levels are true 8-byte random gathers;
-//   * forward: one (level, sample-chunk) per workgroup with the level chosen from blockIdx % 8.  Workgroups
-//     are dealt round-robin over the 8 XCDs, so each XCD's private 4 MiB L2 only ever sees 1/8 of the levels
-//     (2 of 16) instead of the whole 48.8 MB table.  Placement affects speed only, never results.
+//   * forward: one (level, sample-chunk) per workgroup, LEVEL-MAJOR in dispatch order (finest level first): workgroups
+//     are dispatched in order and dealt round-robin over the 8 XCDs, so at any time all XCDs work on the same level and
+//     each private 4 MiB L2 holds just that 4 MB table.  (Binding whole levels to single XCDs -- blockIdx % 8 -- gives the
+//     same locality but the levels cost 0.03 ... 0.10 ms each, and the two XCDs that own two fine levels set the time:
+//     0.85 ms against 0.60 ms; tools/hash_fwd_level_cost.py.)  Placement affects speed only, never results.
 //   * backward: 16 lanes per sample (one per corner x feature) with run-length pre-accumulation, see hash_bwd_kernel;
 //     table gradients are f32 global atomics (memory-side on gfx950, so no level/XCD affinity is attempted there).
 #include "common.h"
@@ -97,6 +99,15 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
         const int64_t slot = bid >> 3;
         level = (bid & 7) + 8 * (int)(slot / chunks);
         chunk = slot % chunks;
+    } else if (mapping == 3) {
+        // level-major: all chunks of level 0, then level 1, ...  Workgroups are dispatched in order and dealt round-robin
+        // to the XCDs, so at any time all 8 XCDs work on the same level (or two neighbouring ones) and every L2 holds
+        // just that 4 MB table -- without binding whole levels to single XCDs, whose costs differ 3x between levels.
+        level = (int)(bid / chunks);
+        chunk = bid % chunks;
+    } else if (mapping == 4) {   // level-major, finest level first (short tail on a cheap level)
+        level = L - 1 - (int)(bid / chunks);
+        chunk = bid % chunks;
     } else if ((L & 7) == 0 && mapping == 1) {   // XCD-affine, levels interleaved (A/B reference)
         const int per = L >> 3;
         const int slot = bid >> 3;
@@ -688,7 +699,7 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     const int64_t chunks = (n + kFwdThreads * kFwdItems - 1) / (kFwdThreads * kFwdItems);
     const int64_t blocks = chunks * g.n_levels;
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
-    static const int mapping = getenv("LSE_HASH_FWD_MAPPING") ? atoi(getenv("LSE_HASH_FWD_MAPPING")) : 0;
+    static const int mapping = getenv("LSE_HASH_FWD_MAPPING") ? atoi(getenv("LSE_HASH_FWD_MAPPING")) : 4;
     hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, lse::as_stream(stream), g, x01,
                        reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping);
     return lse::check_launch("lse_hash_fwd");

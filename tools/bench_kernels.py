@@ -85,4 +85,5 @@ def main():
         med, mn = timeit(f, iters=5)
         print(f"traverse (count+write+sync) median {med:.3f} ms  min {mn:.3f}", flush=True)
 
-main()
+if __name__ == "__main__":
+    main()
