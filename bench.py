@@ -56,30 +56,6 @@ def build_workload(device, seed):
     return model, rb, target.to(device), jitter.to(device)
 
 
-class GradPipeline:
-    """N > 1: the one all-reduce of step k runs asynchronously (RCCL's own stream) while step k+1 marches its rays.
-
-    The sampler reads the occupancy grid only -- no parameters, no gradients -- so `all-reduce(k) -> Adam(k)` can be
-    finished AFTER `sampler(k+1)` without changing a single value: the forward pass of step k+1 still sees the parameters
-    updated by step k.  `flush()` applies the update that is still in flight; bench.py calls it before the timed region
-    starts and before it ends, so exactly K optimizer steps (and K all-reduces) are inside the timed K steps."""
-
-    def __init__(self, opt, world):
-        self.opt, self.world, self.work = opt, world, None
-
-    def start(self):
-        from lsenerf_amd import dist as ldist
-        self.work = ldist.allreduce_grads(self.opt.flat.grad, async_op=True)
-        self.pending = True
-
-    def flush(self):
-        if getattr(self, "pending", False):
-            if self.work is not None:
-                self.work.wait()
-            self.opt.step(grad_scale=1.0 / self.world)
-            self.work, self.pending = None, False
-
-
 def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None, sharded=None):
     from lsenerf_amd import dist as ldist
     rb.origins.grad = None
@@ -89,8 +65,8 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
         rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         t_max=rb.fars.reshape(-1), render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
         alpha_thre=cfg.alpha_thre, jitter=jitter, return_packed=True)
-    if pipeline is not None:
-        pipeline.flush()           # all-reduce + Adam of the previous step, hidden behind the marcher above
+    # (pipelined exchange: the all-reduce + Adam of the previous step finished inside sampling(), right after the marcher,
+    #  through the estimator's after_march_hook -- dist.GradPipeline.attach)
     opt.zero_grad()
     out = model.render_packed(rb, ri, ts, te, packed)
     loss = torch.nn.functional.mse_loss(out["rgb"], target)
@@ -167,7 +143,7 @@ def main():
     _lib.load()
 
     model, rb, target, jitter = build_workload(device, seed=1000 + rank)
-    flat = FlatParams(model.get_param_groups()["fields"])
+    flat = FlatParams(model.get_param_groups()["fields"], total_multiple=world * 64)
     ldist.broadcast_params(flat.data)
     opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
     # N > 1: the gradient all-reduce of step k is hidden behind the ray marcher of step k+1 (GradPipeline).
@@ -179,7 +155,7 @@ def main():
     if mode == "sharded":
         sharded = ldist.ShardedAdamExchange(flat, lr=1e-2, eps=1e-15)
     if mode == "pipelined":
-        pipeline = GradPipeline(opt, world)
+        pipeline = ldist.GradPipeline(opt, world).attach(model.occupancy_grid)
     if mode in ("overlap", "split"):
         grid = model.field.mlp_base_grid
         exchange = ldist.OverlappedGradExchange(flat, grid.params, grid.meta.offsets, split_level=min(6, grid.meta.n_levels - 1))

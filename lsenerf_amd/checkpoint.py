@@ -75,8 +75,11 @@ def convert_pipeline_state(pipeline_state: Dict[str, torch.Tensor]) -> Tuple[Dic
 
 
 def load_nerfstudio_checkpoint(path: str, model: torch.nn.Module, load_step: Optional[int] = None,
-                               drop_camera_optimizer: bool = False) -> Dict[str, object]:
-    """Load a reference checkpoint into ``model``.  ``path`` is a ``.ckpt`` file or a ``nerfstudio_models`` directory
+                               drop_camera_optimizer: bool = False,
+                               optimizers: Optional[Dict[str, object]] = None) -> Dict[str, object]:
+    """Load a reference checkpoint into ``model`` (and, when given, the optimizer states by param-group name into
+    objects with ``load_state_dict`` -- e.g. ``{"fields": FlatAdam}`` -- so that training resumes with its Adam moments
+    and learning-rate schedule position).  ``path`` is a ``.ckpt`` file or a ``nerfstudio_models`` directory
     (then ``load_step`` or the latest step is taken).  ``drop_camera_optimizer`` mirrors the reference's eval mode
     (R:lse_nerf/lse_trainer.py:68-82).  Returns {"step", "missing", "unexpected", "dropped"}; like the reference's
     ``strict=False`` load nothing is raised for missing / unexpected names, but shape mismatches are errors."""
@@ -102,6 +105,10 @@ def load_nerfstudio_checkpoint(path: str, model: torch.nn.Module, load_step: Opt
     for mod in model.modules():
         if hasattr(mod, "_occ_mean_host"):
             mod._occ_mean_host = None
+    if optimizers:   # resume: Adam moments + step count (the lr schedule continues from there)
+        for name, o in optimizers.items():
+            if name in loaded.get("optimizers", {}):
+                o.load_state_dict(loaded["optimizers"][name])
     return {"step": int(loaded["step"]), "missing": list(res.missing_keys), "unexpected": list(res.unexpected_keys),
             "dropped": list(dropped)}
 
@@ -115,7 +122,12 @@ def save_nerfstudio_checkpoint(directory: str, model: torch.nn.Module, step: int
     pipeline = {local_to_reference_key(k): v.detach().cpu().clone() for k, v in model.state_dict().items()}
     opt_state = {}
     for name, o in (optimizers or {}).items():
-        opt_state[name] = o.state_dict() if hasattr(o, "state_dict") else o
+        if hasattr(o, "state_dict"):
+            opt_state[name] = o.state_dict()
+        elif isinstance(o, dict):
+            opt_state[name] = o
+        else:   # a pickled object would make the file unreadable for the weights_only loader above
+            raise TypeError(f"optimizers[{name!r}] must have state_dict() or be a dict of tensors, got {type(o).__name__}")
     path = checkpoint_path(directory, step)
     torch.save({"step": int(step), "pipeline": pipeline, "optimizers": opt_state, "scalers": {}}, path)
     if keep_only_latest:                                   # [UP] Trainer.save_checkpoint(save_only_latest_checkpoint=True)

@@ -4,7 +4,10 @@ The reference wraps the model in torch DDP (R:lse_nerf/lse_pipeline.py:95-98): b
 (including a dead 67 MB table) plus a broadcast of all module buffers on each of its 3 forwards per step.  Here the
 whole gradient is one flat fp32 buffer (lsenerf_amd.optim.FlatParams), so the exchange is a single sum-all-reduce
 over RCCL/xGMI (backend "nccl" on ROCm), and the DDP mean is folded into the Adam kernel's ``grad_scale = 1/W``.
-Occupancy grids stay replicated by updating them from a rank-independent RNG stream (no per-forward broadcast).
+Occupancy grids stay replicated without DDP's per-forward buffer broadcast: ``LSEOccGridEstimator`` draws its update
+cells and jitter from its OWN generator, re-seeded from ``(base seed, step)`` at every update, so every rank (whatever
+its global seed, R:train.py:104 seeds by rank) refreshes the same cells with the same positions from the same
+parameters; ``check_grid_consistency`` asserts it (rehearsed in tools/dp_rehearsal.py and tests/test_dist_cpu.py).
 
 Backend-agnostic: the same code runs on gloo/CPU tensors, which is how the world_size-2 tests exercise it.
 """
@@ -37,6 +40,7 @@ def world_size() -> int:
 
 def shard_rays(n_rays_global: int, rank: int, world: int) -> slice:
     """Rank r takes rays [r*R/W, (r+1)*R/W)."""
+    assert n_rays_global % world == 0, f"{n_rays_global} rays do not split evenly over {world} ranks"
     per = n_rays_global // world
     return slice(rank * per, (rank + 1) * per)
 
@@ -57,7 +61,13 @@ class OverlappedGradExchange:
     slice of the flat gradient buffer is handed to an asynchronous all-reduce (RCCL runs it on its own stream) while the
     second launch computes the remaining levels; ``finish()`` then reduces the rest and waits.  Results are identical to
     ``allreduce_grads`` (same sum over ranks, element for element).  Requires optim.FlatParams (gradients accumulate in
-    place in one buffer)."""
+    place in one buffer).
+
+    Steps with SEVERAL hash backwards (the event configs run three field passes per step -- colour, previous and next
+    event bundle -- hence three hash backwards per ``loss.backward()``, all accumulating into the same table gradient):
+    call ``begin_step(n_backwards)`` before ``backward()``; the early all-reduce is issued only after the first launch of
+    the LAST hash backward, when the fine levels' gradients are final.  Without ``begin_step`` one hash backward per
+    step is assumed, and a second callback in the same step raises instead of reducing a slice twice."""
 
     def __init__(self, flat, table_param: torch.nn.Parameter, level_offsets, split_level: int):
         idx = [i for i, p in enumerate(flat.params) if p is table_param]
@@ -69,6 +79,13 @@ class OverlappedGradExchange:
         self.lo = base + 2 * int(level_offsets[split_level])
         self.hi = base + table_param.numel()
         self._works = []
+        self._expected, self._seen = 1, 0
+
+    def begin_step(self, n_backwards: int = 1):
+        """Arm the exchange for a step whose backward pass runs ``n_backwards`` hash backwards."""
+        assert n_backwards >= 1
+        assert not self._works, "begin_step() while the previous step's exchange is still in flight: call finish() first"
+        self._expected, self._seen = int(n_backwards), 0
 
     def install(self):
         from . import ops
@@ -79,15 +96,23 @@ class OverlappedGradExchange:
         ops.HASH_BWD_SPLIT = None
 
     def _first_part_ready(self):
+        if self._seen >= self._expected:
+            raise RuntimeError(f"OverlappedGradExchange: hash backward #{self._seen + 1} in a step armed for "
+                               f"{self._expected}; call begin_step(n_backwards) before backward()")
+        self._seen += 1
+        if self._seen < self._expected:
+            return          # later hash backwards still add to this slice
         if dist.is_initialized() and dist.get_world_size() > 1:
             self._works.append(dist.all_reduce(self.flat.grad[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Call after backward(): exchanges what the first part did not cover and waits for everything."""
+        seen, self._seen = self._seen, 0
         if not dist.is_initialized() or dist.get_world_size() == 1:
             self._works.clear()
             return
         g = self.flat.grad
+        assert seen in (0, self._expected), f"{seen} hash backwards ran in a step armed for {self._expected}"
         if not self._works:      # the split did not trigger (e.g. no hash backward ran): one plain all-reduce
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             return
@@ -106,8 +131,10 @@ class ShardedAdamExchange:
     parameters; one all-gather then replicates the updated parameters.  Same wire volume as one all-reduce, 1/W of the
     optimizer work and state per rank, and bit-identical parameters on every rank by construction.
 
-    The flat buffers are padded to a multiple of W * 64 floats.  Backends without reduce_scatter (gloo) fall back to
-    all-reduce + slicing, which is what the world-2 CPU test exercises; on RCCL the native collectives run."""
+    The shards are 64-float aligned.  Build the buffers with ``FlatParams(params, total_multiple=W * 64)`` and the
+    collectives run on them in place; otherwise persistent padded staging buffers (allocated once here, never per step) are
+    used.  Backends without reduce_scatter (gloo) fall back to all-reduce + slicing, which is what the world-2 CPU test
+    exercises; on RCCL the native collectives run."""
 
     def __init__(self, flat, lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15, adam_fn=None):
         self.flat = flat
@@ -122,6 +149,7 @@ class ShardedAdamExchange:
         self.exp_avg = torch.zeros(per, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(per, dtype=torch.float32, device=dev)
         self.param_full = torch.zeros(self.padded, dtype=torch.float32, device=dev) if self._pad else None
+        self.grad_full = torch.zeros(self.padded, dtype=torch.float32, device=dev) if self._pad else None   # pad stays 0
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         if adam_fn is None:             # the HIP Adam kernel (lse_adam_step)
@@ -137,7 +165,7 @@ class ShardedAdamExchange:
         g, p = self.flat.grad, self.flat.data
         lo, hi = self.rank * self.per, (self.rank + 1) * self.per
         if self._pad:
-            gp = torch.zeros(self.padded, dtype=torch.float32, device=g.device)
+            gp = self.grad_full
             gp[: g.numel()].copy_(g)
         else:
             gp = g
@@ -165,6 +193,57 @@ class ShardedAdamExchange:
                     pfull[r * self.per:(r + 1) * self.per].copy_(t)
         if self._pad:
             p.copy_(pfull[: p.numel()])
+
+
+class GradPipeline:
+    """N > 1: the one all-reduce of step k runs asynchronously (RCCL's own stream) while step k+1 marches its rays.
+
+    The ray marcher reads the occupancy grid only -- no parameters, no gradients -- so ``all-reduce(k) -> Adam(k)`` can
+    be finished AFTER the marcher of step k+1 without changing a single value: everything that reads parameters in step
+    k+1 (the visibility pre-pass ``sigma_fn`` when ``alpha_thre > 0``, the field pass, the occupancy refresh) still sees
+    the parameters updated by step k.  ``attach(estimator)`` installs ``flush`` as the estimator's ``after_march_hook``,
+    which ``LSEOccGridEstimator.sampling`` calls right after the marcher and BEFORE ``sigma_fn``; callers that drive the
+    sampler themselves call ``flush()`` at that point.  ``flush()`` is idempotent; call it before anything else that reads
+    the parameters (grid refresh, evaluation, checkpoint) and at the end of a timed region, so that exactly K optimizer
+    steps and K all-reduces belong to K steps."""
+
+    def __init__(self, opt, world: Optional[int] = None):
+        self.opt = opt
+        self.world = world if world is not None else world_size()
+        self.work, self.pending = None, False
+
+    def attach(self, estimator):
+        estimator.after_march_hook = self.flush
+        return self
+
+    def start(self):
+        """Call after backward(): launches the asynchronous all-reduce of the flat gradient buffer."""
+        assert not self.pending, "GradPipeline.start() twice without flush()"
+        self.work = allreduce_grads(self.opt.flat.grad, async_op=True)
+        self.pending = True
+
+    def flush(self):
+        """wait -> Adam (mean over ranks folded into grad_scale).  No-op when nothing is in flight."""
+        if self.pending:
+            if self.work is not None:
+                self.work.wait()
+            self.opt.step(grad_scale=1.0 / self.world)
+            self.work, self.pending = None, False
+
+
+def check_grid_consistency(estimator) -> bool:
+    """True iff ``occs`` and ``binaries`` are bit-identical on every rank (the invariant DDP's buffer broadcast provides
+    in the reference, R:lse_nerf/lse_pipeline.py:97)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    ok = True
+    for buf in (estimator.occs, estimator.binaries.to(torch.uint8)):
+        ref = buf.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if torch.equal(ref, buf) else 0], dtype=torch.int32, device=buf.device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        ok = ok and bool(same.item())
+    return ok
 
 
 def broadcast_params(flat_data: torch.Tensor, src: int = 0):

@@ -7,7 +7,11 @@ assertion text, return order); the inherited nerfacc 0.5.2 ``OccGridEstimator`` 
 Differences from the reference, by design:
   * the visibility pre-pass runs under no_grad (the reference builds a dead autograd graph, :14);
   * ``ray_indices`` is int32 internally; ``sampling`` returns int64 like nerfacc unless ``return_packed`` is set;
-  * stratified jitter can be supplied by the caller (``jitter``) so that parity tests share the draw.
+  * stratified jitter can be supplied by the caller (``jitter``) so that parity tests share the draw;
+  * ``_update`` draws its cells and in-cell jitter from the estimator's OWN generator, re-seeded from
+    ``(update_seed, step)``: in data-parallel training every rank refreshes the same cells at the same positions, so the
+    grids stay bit-identical across ranks without DDP's per-forward buffer broadcast (R:lse_nerf/lse_pipeline.py:97;
+    the global RNG is seeded per rank, R:train.py:104).  Pass ``generator=`` to override.
 """
 from __future__ import annotations
 
@@ -51,6 +55,8 @@ class LSEOccGridEstimator(nn.Module):
         self.register_buffer("grid_coords", grid_coords, persistent=False)
         self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
         self._occ_mean_host: Optional[float] = None   # cached occs.mean() (refreshed by _update), saves a sync per forward
+        self.update_seed: int = 0x15E5EED             # base of the rank-independent update stream (same on every rank)
+        self.after_march_hook: Optional[Callable[[], None]] = None   # dist.GradPipeline.flush: runs before sigma_fn
 
     # ---------------------------------------------------------------------------------------------
     def _binaries_u8(self) -> Tensor:
@@ -86,6 +92,9 @@ class LSEOccGridEstimator(nn.Module):
         ray_indices, t_starts, t_ends, packed_info = ops.traverse_grids(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes.contiguous(),
             far_planes.contiguous(), render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane))
+
+        if self.after_march_hook is not None:   # e.g. finish the previous step's all-reduce + Adam (dist.GradPipeline)
+            self.after_march_hook()
 
         # skip invisible space
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None) and t_starts.shape[0] > 0:
@@ -132,22 +141,39 @@ class LSEOccGridEstimator(nn.Module):
             out.append(torch.cat([uniform, occupied], dim=0))
         return out
 
+    def _update_generator(self, step: int) -> torch.Generator:
+        """The rank-independent stream of update ``step``: a fresh generator on the grid's device seeded from
+        (update_seed, step) only -- never from the global RNG, which the trainer seeds per rank."""
+        g = torch.Generator(device=self.occs.device)
+        g.manual_seed((int(self.update_seed) * 1000003 + int(step)) & 0x7FFFFFFFFFFFFFFF)
+        return g
+
     @torch.no_grad()
-    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
-                warmup_steps: int = 256, generator: Optional[torch.Generator] = None) -> None:
-        """nerfacc ``OccGridEstimator._update``.  Index generation is torch plumbing; the EMA-max and the
-        binarisation run in the HIP kernels (lse_occ_update_cells / lse_occ_binarize)."""
+    def _update_samples(self, step: int, warmup_steps: int, generator: torch.Generator) -> List[Tuple[Tensor, Tensor]]:
+        """Per level: (cell indices, one jittered position per cell in world coordinates).  Pure torch (runs on any
+        device): this is the part of ``_update`` that consumes random numbers."""
         if step < warmup_steps:
             lvl_indices = self._get_all_cells()
         else:
             lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4, generator)
         dev = self.occs.device
+        out = []
         for lvl, indices in enumerate(lvl_indices):
             grid_coords = self.grid_coords[indices]
             u = torch.rand(grid_coords.shape, dtype=torch.float32, device=dev, generator=generator)
             x = (grid_coords + u) / self.resolution
             ab = self.aabbs[lvl]
-            x = ab[:3] + x * (ab[3:] - ab[:3])
+            out.append((indices, ab[:3] + x * (ab[3:] - ab[:3])))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256, generator: Optional[torch.Generator] = None) -> None:
+        """nerfacc ``OccGridEstimator._update``.  Index generation is torch plumbing; the EMA-max and the
+        binarisation run in the HIP kernels (lse_occ_update_cells / lse_occ_binarize)."""
+        if generator is None:
+            generator = self._update_generator(step)
+        for lvl, (indices, x) in enumerate(self._update_samples(step, warmup_steps, generator)):
             occ = occ_eval_fn(x).squeeze(-1)
             cell_ids = (lvl * self.cells_per_lvl + indices).contiguous()
             ops.occ_update_cells(self.occs, cell_ids, occ.contiguous().float(), ema_decay)

@@ -19,7 +19,8 @@ from . import ops
 
 
 class FlatParams:
-    def __init__(self, params: Iterable[nn.Parameter], align: int = 64):
+    def __init__(self, params: Iterable[nn.Parameter], align: int = 64, total_multiple: int = 1):
+        """``total_multiple``: round the buffer length up (e.g. W * 64 so that dist.ShardedAdamExchange shards it in place)."""
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         assert len(self.params) > 0
         dev = self.params[0].device
@@ -28,6 +29,7 @@ class FlatParams:
             assert p.dtype == torch.float32 and p.device == dev
             offs.append(total)
             total += (p.numel() + align - 1) // align * align
+        total = (total + total_multiple - 1) // total_multiple * total_multiple
         self.offsets, self.numel = offs, total
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -72,3 +74,40 @@ class FlatAdam:
         self.step_count += 1
         ops.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                       self.eps, self.step_count, grad_scale)
+
+    # -- resume (nerfstudio saves ``optimizers: {"fields": optimizer.state_dict()}``, R:lse_nerf/lse_trainer.py:85-122) ------
+    def state_dict(self) -> dict:
+        """torch.optim.Adam-style state dict (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` + one param group), so
+        a checkpoint written from here loads into ``torch.optim.Adam`` over the same parameter list and vice versa."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.flat.params))),
+                 "initial_lr": self.lr_init, "lr_final": self.lr_final, "max_steps": self.max_steps}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        state = sd["state"]
+        assert len(state) in (0, len(self.flat.params)), "optimizer state does not match the parameter list"
+        steps = set()
+        for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            n = p.numel()
+            assert tuple(st["exp_avg"].shape) == tuple(p.shape), f"state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}"
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        assert len(steps) <= 1, f"parameters disagree on the step count: {steps}"
+        if steps:
+            self.step_count = steps.pop()
+        g = sd["param_groups"][0]
+        self.lr_init = g.get("initial_lr", self.lr_init)
+        self.lr_final = g.get("lr_final", self.lr_final)
+        self.max_steps = g.get("max_steps", self.max_steps)

@@ -85,3 +85,36 @@ def test_reference_style_file_with_dead_table_half_params_and_ddp_prefix(tmp_pat
     torch.save({"foo": 1}, f)
     with pytest.raises(ValueError, match="not a nerfstudio checkpoint"):
         ck.load_nerfstudio_checkpoint(f, m)
+
+
+def test_flat_adam_state_survives_a_checkpoint_round_trip(tmp_path):
+    """Training resume: FlatAdam's moments / step count are stored in torch.optim.Adam's layout under the reference's
+    "fields" param-group name and come back through the weights_only loader (parity unpinned: the reference ships no
+    checkpoint, the layout follows nerfstudio 0.3.2's Trainer.save_checkpoint)."""
+    from lsenerf_amd.checkpoint import load_nerfstudio_checkpoint, save_nerfstudio_checkpoint
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
+    flat = FlatParams(model.parameters())
+    opt = FlatAdam(flat, lr=1e-2, lr_final=1e-4, max_steps=100)
+    opt.exp_avg.copy_(torch.randn_like(opt.exp_avg))
+    opt.exp_avg_sq.copy_(torch.rand_like(opt.exp_avg_sq))
+    opt.step_count = 37
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == 4
+    assert sd["state"][0]["exp_avg"].shape == model[0].weight.shape
+    ref = torch.optim.Adam(model.parameters(), lr=1e-2)
+    ref.load_state_dict(sd)                                    # the layout is torch.optim.Adam's own
+    save_nerfstudio_checkpoint(str(tmp_path), model, 37, optimizers={"fields": opt})
+    with pytest.raises(TypeError):
+        save_nerfstudio_checkpoint(str(tmp_path), model, 38, optimizers={"fields": object()})
+    model2 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
+    flat2 = FlatParams(model2.parameters())
+    opt2 = FlatAdam(flat2, lr=1e-2, lr_final=1e-4, max_steps=100)
+    res = load_nerfstudio_checkpoint(str(tmp_path), model2, optimizers={"fields": opt2})
+    assert res["step"] == 37 and opt2.step_count == 37
+    sd2 = opt2.state_dict()
+    for i in sd["state"]:                                      # (the 64-float alignment pads between parameters carry no state)
+        assert torch.equal(sd2["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert torch.equal(sd2["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+    assert abs(opt2.current_lr() - opt.current_lr()) < 1e-12

@@ -186,3 +186,214 @@ def test_sharded_adam_equals_full_batch_and_replicates(tmp_path):
         ((model(x) - y) ** 2).mean().backward()
         _adam_cpu(flat, state, 1e-2, 1.0, step)
     assert torch.allclose(p0, flat.data, atol=1e-6)
+
+
+def _multi_backward_worker(rank, world, port, out):
+    """Event configs: three field passes (colour / previous / next bundle) -> three hash backwards per loss.backward(),
+    all accumulating into the same table gradient.  The early all-reduce may only start after the LAST one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist, ops
+    from lsenerf_amd.optim import FlatParams
+    ldist.init_from_env("gloo")
+    torch.manual_seed(0)
+    other = torch.nn.Parameter(torch.randn(100))
+    table = torch.nn.Parameter(torch.randn(2 * 96))
+    flat = FlatParams([other, table])
+    ex = ldist.OverlappedGradExchange(flat, table, level_offsets=(0, 32, 64, 96), split_level=1)
+    ex.install()
+    res = []
+    for mode in ("armed", "plain"):
+        flat.zero_grad()
+        g = torch.Generator().manual_seed(20 + rank)
+        if mode == "armed":
+            ex.begin_step(3)
+        for _ in range(3):                          # three accumulating hash backwards: fine levels, callback, coarse levels
+            table.grad[64:].add_(torch.randn(128, generator=g))
+            if mode == "armed":
+                ops.HASH_BWD_SPLIT[1]()
+            table.grad[:64].add_(torch.randn(64, generator=g))
+        other.grad.add_(torch.randn(100, generator=g))
+        if mode == "armed":
+            ex.finish()
+        else:
+            ldist.allreduce_grads(flat.grad)
+        res.append(flat.grad.clone())
+    # an un-armed second callback in one step must raise instead of reducing the slice twice
+    ex.begin_step(1)
+    ops.HASH_BWD_SPLIT[1]()
+    try:
+        ops.HASH_BWD_SPLIT[1]()
+        raised = False
+    except RuntimeError:
+        raised = True
+    ex.finish()
+    ex.uninstall()
+    if rank == 0:
+        torch.save({"res": res, "raised": raised}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_with_three_hash_backwards_per_step(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_multi_backward_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    armed, plain = got["res"]
+    assert torch.equal(armed, plain)
+    assert got["raised"]
+
+
+class _ToyOpt:
+    """FlatAdam's interface on CPU tensors (the HIP Adam kernel needs a GPU)."""
+
+    def __init__(self, flat):
+        self.flat, self.step_count = flat, 0
+        self.state = {"m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)}
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        _adam_cpu(self.flat, self.state, 1e-2, grad_scale, self.step_count)
+
+
+class _ToyEstimator:
+    """Only what GradPipeline touches: the hook slot and a `sampling` that fires it between marcher and sigma_fn."""
+
+    def __init__(self):
+        self.after_march_hook = None
+
+    def sampling(self, sigma_fn):
+        if self.after_march_hook is not None:
+            self.after_march_hook()
+        return sigma_fn()
+
+
+def _pipeline_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    ldist.init_from_env("gloo")
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+    sl = ldist.shard_rays(64, rank, world)
+    finals, seen = [], []
+    for mode in ("pipelined", "plain"):
+        model = _model()
+        flat = FlatParams(model.parameters())
+        ldist.broadcast_params(flat.data)
+        opt = _ToyOpt(flat)
+        est = _ToyEstimator()
+        pipe = ldist.GradPipeline(opt, world).attach(est) if mode == "pipelined" else None
+        for step in range(4):
+            # the visibility pre-pass reads the parameters: it must see the update of the previous step
+            seen.append(est.sampling(lambda: float(flat.data.sum())))
+            opt.zero_grad()
+            ((model(x[sl]) - y[sl]) ** 2).mean().backward()
+            if pipe is not None:
+                pipe.start()
+            else:
+                ldist.allreduce_grads(flat.grad)
+                opt.step(grad_scale=1.0 / world)
+        if pipe is not None:
+            pipe.flush()
+            pipe.flush()      # idempotent
+            assert opt.step_count == 4
+        finals.append(flat.data.clone())
+    if rank == 0:
+        torch.save({"finals": finals, "seen": seen}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_pipeline_is_value_identical_to_the_blocking_exchange(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert torch.equal(got["finals"][0], got["finals"][1])
+    assert got["seen"][:4] == got["seen"][4:]          # sigma_fn saw the same parameters in both schedules
+
+
+def _sharded_inplace_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    ldist.init_from_env("gloo")
+    res = []
+    for mult in (1, world * 64):
+        model = _model()
+        flat = FlatParams(model.parameters(), total_multiple=mult)
+        ex = ldist.ShardedAdamExchange(flat, lr=1e-2, adam_fn=_adam_fn_cpu)
+        if mult > 1:
+            assert ex._pad == 0 and ex.grad_full is None and ex.param_full is None      # collectives run in place
+        g = torch.Generator().manual_seed(1)
+        x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+        sl = ldist.shard_rays(64, rank, world)
+        for _ in range(3):
+            flat.zero_grad()
+            ((model(x[sl]) - y[sl]) ** 2).mean().backward()
+            ex.step()
+        res.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adam_in_place_buffers_match_the_staged_ones(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_sharded_inplace_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    staged, inplace = torch.load(out)
+    assert torch.equal(staged, inplace)
+
+
+def _grid_rng_worker(rank, world, port, out):
+    """R:train.py:104 seeds every rank differently; the occupancy refresh must not care."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.grid_estimator import LSEOccGridEstimator
+    ldist.init_from_env("gloo")
+    torch.manual_seed(1234 + rank)                        # per-rank global RNG, as in the reference
+    est = LSEOccGridEstimator([-1.0, -1, -1, 1, 1, 1], resolution=16, levels=2)
+    est.occs.copy_(torch.rand(est.occs.shape, generator=torch.Generator().manual_seed(5)))
+    est.binaries.copy_((est.occs > 0.5).view(est.binaries.shape))
+    torch.rand(rank + 1)                                  # ranks have consumed different amounts of global randomness
+    same = []
+    for step in (0, 320):                                 # warm-up branch (all cells) and the sampled branch
+        cells = est._update_samples(step, 256, est._update_generator(step))
+        blob = torch.cat([torch.cat([i.float(), x.reshape(-1)]) for i, x in cells])
+        n = torch.tensor([blob.numel()])
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        ok = all(int(v) == int(n) for v in ns)
+        if ok:
+            ref = blob.clone()
+            dist.broadcast(ref, src=0)
+            ok = torch.equal(ref, blob)
+        same.append(ok)
+    consistent = ldist.check_grid_consistency(est)
+    est.occs[0] += float(rank)                            # and the checker notices a divergence
+    broken = ldist.check_grid_consistency(est)
+    if rank == 1:
+        torch.save({"same": same, "consistent": consistent, "broken": broken}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_occupancy_refresh_is_rank_independent(tmp_path):
+    out = str(tmp_path / "r1.pt")
+    mp.spawn(_grid_rng_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["same"] == [True, True]
+    assert got["consistent"] is True and got["broken"] is False
+
+
+def test_shard_rays_rejects_uneven_splits():
+    from lsenerf_amd.dist import shard_rays
+    with pytest.raises(AssertionError):
+        shard_rays(4097, 0, 2)
