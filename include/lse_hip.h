@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSE_ABI_VERSION 1
+#define LSE_ABI_VERSION 2
 
 #define LSE_OK 0
 #define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
@@ -103,6 +103,10 @@ int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t
 int lse_visibility_mask(const float *t_starts, const float *t_ends, const float *sigmas,
                         const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
                         uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
+/* nerfacc.render_visibility_from_alpha (the alpha_fn branch, R:lse_nerf/lse_grid_estimator.py:128-138): same scan on
+ * per-sample opacities; T_k = prod_{i<k} (1 - alpha_i), mask = T >= early_stop_eps && alpha >= alpha_thre. */
+int lse_visibility_mask_alpha(const float *alphas, const int64_t *packed_info, int32_t n_rays, float early_stop_eps,
+                              float alpha_thre, uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
 
 /* mask compaction at R:lse_nerf/lse_grid_estimator.py:139-143 (order preserving, per ray). */
 int lse_compact_samples(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info,
@@ -138,6 +142,35 @@ int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, c
 int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                         float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end,
                         int64_t n, lse_stream_t stream);
+
+/* Kernel selection of the hash backward as CALL ARGUMENTS (so that two variants can be compared inside one process):
+ *   impl          1 = lane-per-sample kernel with the per-wave LDS sector cache (default); 0 = 16-lanes-per-sample kernel
+ *   gran          cache slot size of impl 1: 2 = 32-B sectors x 512 slots (default), 3 = 64-B lines x 256 slots
+ *   few_runs      impl 1: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
+ *   second_probe  impl 1: probe the neighbouring slot before falling back to memory (default 0)
+ *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
+ *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)
+ *   dbg           timing experiments only (bit 0: skip flush atomics, bit 1: skip run ends, bit 2: skip the scan) -> WRONG results
+ * lse_hash_bwd / lse_hash_bwd_levels use lse_hash_bwd_default_opts(). */
+typedef struct lse_hash_bwd_opts {
+    int32_t impl, gran, few_runs, second_probe, rounds, dbg;
+    float interleave_from_scale;
+} lse_hash_bwd_opts;
+void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
+int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
+                    float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end, int64_t n,
+                    const lse_hash_bwd_opts *opts /* NULL = defaults */, lse_stream_t stream);
+
+/* Development knobs that are not part of any call signature, readable and writable at run time (no environment
+ * variables are consulted after the library is loaded):
+ *   "hash_fwd_mapping"  workgroup -> (level, chunk) order of lse_hash_fwd: 4 = level-major, finest level first (default),
+ *                       3 = level-major coarse first, 0 / 1 = XCD-bound levels, 2 = level-interleaved
+ *   "mlp_fwd_cfg" / "mlp_bwd_cfg"  CT * 10 + NW tile shape of the fused MLP kernels (default 28)
+ *   "mlp_bwd_share"     1 = weight-gradient tiles sliced over the waves of a workgroup (default), 0 = every wave keeps all
+ *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
+ * Returns LSE_E_INVALID for an unknown name.  Results never depend on these (speed only). */
+int lse_set_option(const char *name, int64_t value);
+int lse_get_option(const char *name, int64_t *value);
 
 /* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
@@ -197,6 +230,23 @@ int lse_volrend_bwd(const float *t_starts, const float *t_ends, const float *sig
                     int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, const float *weights,
                     const float *d_out_rgb, const float *d_out_acc, const float *d_out_depth_num, float *d_sigmas,
                     float *d_rgb, lse_stream_t stream);
+
+/* lse_volrend_fwd + the DepthRenderer("expected") epilogue of R:lse_nerf/lsenerf.py:315-317 in the same call:
+ * out_depth[r] = clip(out_depth_num[r] / (out_acc[r] + 1e-10), lo, hi) with (lo, hi) the global min / max of the interval
+ * mid-points (nerfstudio clips to steps.min() / steps.max()); samples are sorted inside a ray, so the range is reduced
+ * from the per-ray first / last mid-point (mid_range [R,2], workspace) instead of two passes over all N samples.
+ * depth_range[2] (nullable) receives (lo, hi) for the backward. */
+int lse_volrend_depth_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                          int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, float *weights, float *out_rgb,
+                          float *out_acc, float *out_depth_num, float *mid_range, float *out_depth, float *depth_range,
+                          lse_stream_t stream);
+/* nerfacc.render_weight_from_density alone (R:lse_nerf/lsenerf.py:301-306): weights, and optionally transmittance and
+ * alphas per sample; the backward takes a per-sample d_weights (the generic route: renderers applied by the caller). */
+int lse_render_weight_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const int64_t *packed_info,
+                          int32_t n_rays, float *weights, float *trans, float *alphas, lse_stream_t stream);
+int lse_render_weight_bwd(const float *t_starts, const float *t_ends, const float *sigmas, const int64_t *packed_info,
+                          int32_t n_rays, const float *weights, const float *d_weights, float *d_sigmas,
+                          lse_stream_t stream);
 
 /* ---- occupancy grid (nerfacc OccGridEstimator._update) --------------------------- */
 /* occs[id] = max(occs[id]*ema_decay, occ_new); duplicate ids resolve to the maximum over the duplicates (upstream:

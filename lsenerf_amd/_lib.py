@@ -16,12 +16,17 @@ LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
 LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
 LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
-LSE_ABI_VERSION = 1
+LSE_ABI_VERSION = 2
 
 
 class GridDesc(Structure):
     _fields_ = [("n_levels", c_int32), ("n_features", c_int32), ("offsets", c_uint32 * (LSE_MAX_GRID_LEVELS + 1)),
                 ("scales", c_float * LSE_MAX_GRID_LEVELS), ("resolutions", c_uint32 * LSE_MAX_GRID_LEVELS)]
+
+
+class HashBwdOpts(Structure):
+    _fields_ = [("impl", c_int32), ("gran", c_int32), ("few_runs", c_int32), ("second_probe", c_int32), ("rounds", c_int32),
+                ("dbg", c_int32), ("interleave_from_scale", c_float)]
 
 
 class MlpDesc(Structure):
@@ -39,6 +44,7 @@ SIGNATURES = {
     "lse_compact_ray_slots": [P, P, I64, P, I32, P, P, P, P],
     "lse_pack_info_from_counts": [P, I32, P, P, P],
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
+    "lse_visibility_mask_alpha": [P, P, I32, F32, F32, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
     "lse_positions_fwd": [P, P, P, P, P, I64, I32, P, P, P, P],
     "lse_positions_bwd": [P, P, P, P, P, I64, I32, P, P, P, P],
@@ -46,6 +52,9 @@ SIGNATURES = {
     "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P],
     "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P],
     "lse_hash_bwd_levels": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P],
+    "lse_hash_bwd_ex": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, POINTER(HashBwdOpts), P],
+    "lse_set_option": [c_char_p, I64],
+    "lse_get_option": [c_char_p, POINTER(c_int64)],
     "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
     "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, I64, P],
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
@@ -59,6 +68,9 @@ SIGNATURES = {
     "lse_density_bwd": [P, P, F32, P, P, I64, P],
     "lse_volrend_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P],
     "lse_volrend_bwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P],
+    "lse_volrend_depth_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P, P],
+    "lse_render_weight_fwd": [P, P, P, P, I32, P, P, P, P],
+    "lse_render_weight_bwd": [P, P, P, P, I32, P, P, P, P],
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],
@@ -89,10 +101,18 @@ def load():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = c_int32
+    lib.lse_hash_bwd_default_opts.restype = None
+    lib.lse_hash_bwd_default_opts.argtypes = [POINTER(HashBwdOpts)]
     v = lib.lse_abi_version()
     if v != LSE_ABI_VERSION:
         raise LseHipError(f"liblse_hip.so ABI version {v} != binding version {LSE_ABI_VERSION}")
     _lib = lib
+    # developer convenience for A/B scripts: LSE_OPT_<NAME>=<int> seeds the library's run-time options once, here on the
+    # Python side (the library itself reads no environment variables)
+    for k, val in os.environ.items():
+        if k.startswith("LSE_OPT_"):
+            if lib.lse_set_option(k[len("LSE_OPT_"):].lower().encode(), int(val)) != 0:
+                raise LseHipError(f"{k}: {lib.lse_last_error().decode()}")
     return lib
 
 
@@ -116,3 +136,20 @@ def call(name: str, *args):
         rc = getattr(lib, name)(*args)
     if rc != 0:
         raise LseHipError(f"{name} failed (rc={rc}): {lib.lse_last_error().decode()}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Run-time development knob of the library (include/lse_hip.h: lse_set_option); speed only, never results."""
+    call("lse_set_option", name.encode(), int(value))
+
+
+def get_option(name: str) -> int:
+    v = c_int64(0)
+    call("lse_get_option", name.encode(), ctypes.byref(v))
+    return int(v.value)
+
+
+def hash_bwd_default_opts() -> HashBwdOpts:
+    o = HashBwdOpts()
+    load().lse_hash_bwd_default_opts(ctypes.byref(o))
+    return o

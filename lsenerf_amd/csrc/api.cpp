@@ -1,6 +1,7 @@
 // Error reporting + version of the C-ABI (include/lse_hip.h).
 #include "common.h"
 #include <string.h>
+#include <atomic>
 
 namespace lse {
 static thread_local char g_err[512] = "";
@@ -13,6 +14,48 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 }  // namespace lse
+
+namespace lse {
+// run-time development knobs (include/lse_hip.h: lse_set_option); plain ints, read at every launch
+struct Option { const char *name; std::atomic<int64_t> value; };
+static Option g_options[] = {
+    {"hash_fwd_mapping", {4}},
+    {"mlp_fwd_cfg", {28}},
+    {"mlp_bwd_cfg", {28}},
+    {"mlp_bwd_share", {1}},
+    {"traverse_vec", {1}},
+};
+int64_t option(const char *name)
+{
+    for (auto &o : g_options)
+        if (!strcmp(o.name, name)) return o.value.load(std::memory_order_relaxed);
+    return 0;
+}
+}  // namespace lse
+
+extern "C" int lse_set_option(const char *name, int64_t value)
+{
+    LSE_REQUIRE(name, "lse_set_option: null name");
+    for (auto &o : lse::g_options)
+        if (!strcmp(o.name, name)) {
+            o.value.store(value, std::memory_order_relaxed);
+            return LSE_OK;
+        }
+    lse::set_error("lse_set_option: unknown option '%s'", name);
+    return LSE_E_INVALID;
+}
+
+extern "C" int lse_get_option(const char *name, int64_t *value)
+{
+    LSE_REQUIRE(name && value, "lse_get_option: null pointer");
+    for (auto &o : lse::g_options)
+        if (!strcmp(o.name, name)) {
+            *value = o.value.load(std::memory_order_relaxed);
+            return LSE_OK;
+        }
+    lse::set_error("lse_get_option: unknown option '%s'", name);
+    return LSE_E_INVALID;
+}
 
 extern "C" const char *lse_last_error(void) { return lse::g_err; }
 extern "C" int lse_abi_version(void) { return LSE_ABI_VERSION; }

@@ -10,6 +10,7 @@
 namespace lse {
 
 void set_error(const char *fmt, ...);
+int64_t option(const char *name);   // run-time development knob (lse_set_option), 0 for unknown names
 
 static inline hipStream_t as_stream(lse_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -699,22 +699,48 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     const int64_t chunks = (n + kFwdThreads * kFwdItems - 1) / (kFwdThreads * kFwdItems);
     const int64_t blocks = chunks * g.n_levels;
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
-    static const int mapping = getenv("LSE_HASH_FWD_MAPPING") ? atoi(getenv("LSE_HASH_FWD_MAPPING")) : 4;
+    const int mapping = (int)lse::option("hash_fwd_mapping");
     hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, lse::as_stream(stream), g, x01,
                        reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping);
     return lse::check_launch("lse_hash_fwd");
 }
 
+extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
+{
+    if (!o) return;
+    o->impl = 1;           // lane-per-sample + LDS sector cache
+    o->gran = 2;           // 512 slots of one 32-B sector
+    o->few_runs = 6;       // tuned on MI355X: 4..8 equal, 16 already slower
+    o->second_probe = 0;
+    o->rounds = 32;
+    o->dbg = 0;
+    o->interleave_from_scale = 1e30f;   // measured negative on MI355X (same-address lanes of one atomic instruction serialise)
+}
+
 extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                             float *dtable, float *dx, int64_t n, lse_stream_t stream)
 {
-    return lse_hash_bwd_levels(desc, x01, dy, table, dtable, dx, 0, 0, desc ? desc->n_levels : 0, n, stream);
+    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, 0, 0, desc ? desc->n_levels : 0, n, nullptr, stream);
 }
 
 extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                                    float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin,
                                    int32_t level_end, int64_t n, lse_stream_t stream)
 {
+    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, dx_accumulate, level_begin, level_end, n, nullptr, stream);
+}
+
+extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
+                               float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end,
+                               int64_t n, const lse_hash_bwd_opts *opts, lse_stream_t stream)
+{
+    lse_hash_bwd_opts o;
+    lse_hash_bwd_default_opts(&o);
+    if (opts) o = *opts;
+    LSE_REQUIRE(o.impl == 0 || o.impl == 1, "lse_hash_bwd: opts.impl must be 0 or 1");
+    LSE_REQUIRE(o.gran == 2 || o.gran == 3, "lse_hash_bwd: opts.gran must be 2 or 3");
+    LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
+    LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
     int rc = fill_params(desc, g, "lse_hash_bwd");
     if (rc) return rc;
@@ -728,21 +754,15 @@ extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, 
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(x01 && dy && dtable, "lse_hash_bwd: null pointer");
     LSE_REQUIRE(!dx || table, "lse_hash_bwd: dx requested but table is null");
-    // Levels with scale >= il_scale use the interleaved (4 consecutive samples per instruction) mapping.  Measured
-    // negative on MI355X (same-address lanes inside one atomic instruction serialise): default = never.
-    static const float il_scale = getenv("LSE_HASH_BWD_INTERLEAVE_SCALE") ? (float)atof(getenv("LSE_HASH_BWD_INTERLEAVE_SCALE")) : 1e30f;
-    static const int rounds = getenv("LSE_HASH_BWD_ROUNDS") ? atoi(getenv("LSE_HASH_BWD_ROUNDS")) : 32;
+    const float il_scale = o.interleave_from_scale;
+    const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
     // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
-    static const int impl = getenv("LSE_HASH_BWD_IMPL") ? atoi(getenv("LSE_HASH_BWD_IMPL")) : 1;
     bool lines_ok = true;
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
-    static const int dbg = getenv("LSE_HASH_BWD_DBG") ? atoi(getenv("LSE_HASH_BWD_DBG")) : 0;   // timing experiments only
     if (impl == 1 && lines_ok) {
-        static const int few_runs = getenv("LSE_HASH_BWD_FEW") ? atoi(getenv("LSE_HASH_BWD_FEW")) : 6;   // tuned on MI355X: 4..8 equal, 16 already slower
-        static const int second_probe = getenv("LSE_HASH_BWD_PROBE2") ? atoi(getenv("LSE_HASH_BWD_PROBE2")) : 0;
-        static const int gran = getenv("LSE_HASH_BWD_GRAN") ? atoi(getenv("LSE_HASH_BWD_GRAN")) : 2;
+        const int few_runs = o.few_runs, second_probe = o.second_probe, gran = o.gran;
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);

@@ -780,12 +780,6 @@ int check_desc(const lse_mlp_desc *d, const char *who)
     return LSE_OK;
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
 int launch_fwd_cfg(const MlpArgs &a, hipStream_t st)
 {
@@ -800,7 +794,7 @@ int launch_fwd_cfg(const MlpArgs &a, hipStream_t st)
 template <int KIN, int WIDTH, int NHL, int INL>
 int launch_fwd(const MlpArgs &a, hipStream_t st)
 {
-    static const int cfg = env_int("LSE_MLP_FWD_CFG", 28);   // CT*10 + NW
+    const int cfg = (int)lse::option("mlp_fwd_cfg");   // CT*10 + NW
     switch (cfg) {
     case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
     case 216: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
@@ -843,7 +837,7 @@ int launch_bwd_cfg(const MlpArgs &a, hipStream_t st)
 template <int KIN, int WIDTH, int NHL, int INL>
 int launch_bwd(const MlpArgs &a, hipStream_t st)
 {
-    static const int cfg = env_int("LSE_MLP_BWD_CFG", 28);   // CT*10 + NW
+    const int cfg = (int)lse::option("mlp_bwd_cfg");   // CT*10 + NW
     switch (cfg) {
     case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
     case 24: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 4>(a, st);

@@ -392,8 +392,7 @@ __global__ __launch_bounds__(256) void compact_slots_kernel(const float *__restr
 
 static int vec_march_enabled()
 {
-    static const int v = getenv("LSE_TRAVERSE_VEC") ? atoi(getenv("LSE_TRAVERSE_VEC")) : 1;
-    return v;
+    return (int)lse::option("traverse_vec");
 }
 
 }  // namespace

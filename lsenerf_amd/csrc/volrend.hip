@@ -27,13 +27,16 @@ __global__ __launch_bounds__(256) void volrend_fwd_kernel(const float *__restric
                                                           const float *__restrict__ sigma, const float *__restrict__ rgb,
                                                           int rgb_stride, const int64_t *__restrict__ packed, int n_rays,
                                                           float *__restrict__ weights, float *__restrict__ out_rgb,
-                                                          float *__restrict__ out_acc, float *__restrict__ out_dep)
+                                                          float *__restrict__ out_acc, float *__restrict__ out_dep,
+                                                          float *__restrict__ trans, float *__restrict__ alphas,
+                                                          float *__restrict__ mid_range)
 {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     const int lane = threadIdx.x & 63;
     const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
     float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f, ad = 0.f;
+    float mlo = INFINITY, mhi = -INFINITY;   // smallest / largest interval mid-point of this ray (DepthRenderer's clip range)
     for (int64_t base = 0; base < cnt; base += 64) {
         const int64_t i = s0 + base + lane;
         const bool valid = base + lane < cnt;
@@ -47,6 +50,10 @@ __global__ __launch_bounds__(256) void volrend_fwd_kernel(const float *__restric
         const float w = valid ? T * alpha : 0.f;
         if (valid) {
             weights[i] = w;
+            if (trans) trans[i] = T;
+            if (alphas) alphas[i] = alpha;
+            mlo = fminf(mlo, (a + b) * 0.5f);
+            mhi = fmaxf(mhi, (a + b) * 0.5f);
             if (rgb) {
                 const float *c = rgb + i * rgb_stride;
                 ar = fmaf(w, c[0], ar);
@@ -60,10 +67,51 @@ __global__ __launch_bounds__(256) void volrend_fwd_kernel(const float *__restric
     }
     ar = lse::wave_sum(ar); ag = lse::wave_sum(ag); ab = lse::wave_sum(ab);
     aw = lse::wave_sum(aw); ad = lse::wave_sum(ad);
+    if (mid_range) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mlo = fminf(mlo, __shfl_xor(mlo, off, 64));
+            mhi = fmaxf(mhi, __shfl_xor(mhi, off, 64));
+        }
+    }
     if (lane == 0) {
         if (out_rgb) { out_rgb[ray * 3 + 0] = ar; out_rgb[ray * 3 + 1] = ag; out_rgb[ray * 3 + 2] = ab; }
         if (out_acc) out_acc[ray] = aw;
         if (out_dep) out_dep[ray] = ad;
+        if (mid_range) { mid_range[2 * ray] = mlo; mid_range[2 * ray + 1] = mhi; }
+    }
+}
+
+// DepthRenderer("expected") epilogue (nerfstudio 0.3.2): depth = num / (acc + 1e-10), clipped to the
+// GLOBAL [min, max] of the interval mid-points.  Samples are sorted inside a ray, so the global range is the min / max over
+// the per-ray ranges the forward kernel leaves in mid_range[R][2] -- an O(R) reduction in one workgroup instead of two
+// reductions over all N samples.  range_out[2] keeps (lo, hi) for the backward.
+__global__ __launch_bounds__(1024) void depth_finish_kernel(const float *__restrict__ num, const float *__restrict__ acc,
+                                                            const float *__restrict__ mid_range, int n_rays,
+                                                            float *__restrict__ depth, float *__restrict__ range_out)
+{
+    __shared__ float s_lo[16], s_hi[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int r = threadIdx.x; r < n_rays; r += 1024) {
+        lo = fminf(lo, mid_range[2 * r]);
+        hi = fmaxf(hi, mid_range[2 * r + 1]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    lo = s_lo[0]; hi = s_hi[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+    if (threadIdx.x == 0 && range_out) { range_out[0] = lo; range_out[1] = hi; }
+    const bool any = lo <= hi;     // no sample at all: nerfstudio's clip is skipped (steps is empty)
+    for (int r = threadIdx.x; r < n_rays; r += 1024) {
+        float d = num[r] / (acc[r] + 1e-10f);
+        if (any) d = fminf(fmaxf(d, lo), hi);
+        depth[r] = d;
     }
 }
 
@@ -73,7 +121,7 @@ __global__ __launch_bounds__(256) void volrend_bwd_kernel(const float *__restric
                                                           const float *__restrict__ weights,
                                                           const float *__restrict__ g_rgb, const float *__restrict__ g_acc,
                                                           const float *__restrict__ g_dep, float *__restrict__ d_sigma,
-                                                          float *__restrict__ d_rgb)
+                                                          float *__restrict__ d_rgb, const float *__restrict__ g_w)
 {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -100,6 +148,7 @@ __global__ __launch_bounds__(256) void volrend_bwd_kernel(const float *__restric
             const float a = ts[i], b = te[i];
             dt = b - a;
             dw = ga + gd * ((a + b) * 0.5f);
+            if (g_w) dw += g_w[i];            // per-sample gradient of the weights themselves (render_weight_from_density)
             if (rgb && g_rgb) {
                 const float *c = rgb + i * rgb_stride;
                 dw += gr * c[0] + gg * c[1] + gb * c[2];
@@ -128,7 +177,7 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
                                                          const float *__restrict__ sigma,
                                                          const int64_t *__restrict__ packed, int n_rays, float eps,
                                                          float alpha_thre, uint8_t *__restrict__ mask,
-                                                         int64_t *__restrict__ new_cnts)
+                                                         int64_t *__restrict__ new_cnts, int from_alpha)
 {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -140,11 +189,16 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
         const int64_t i = s0 + base + lane;
         const bool valid = base + lane < cnt;
         float a = 0.f, b = 0.f, sg = 0.f;
-        if (valid) { a = ts[i]; b = te[i]; sg = sigma[i]; }
-        const float sd = sg * (b - a);
+        if (valid) {
+            sg = sigma[i];
+            if (!from_alpha) { a = ts[i]; b = te[i]; }
+        }
+        // from_alpha (nerfacc.render_visibility_from_alpha): `sigma` holds opacities; T_k = prod_{i<k} (1 - alpha_i) is
+        // formed as exp(-sum -log(1 - alpha_i)) with the same scan, the alpha threshold is tested on the input value itself
+        const float sd = from_alpha ? -log1pf(-fminf(sg, 1.f)) : sg * (b - a);
         const float incl = lse::wave_inclusive_sum(sd);
         const float T = expf(-((incl - sd) + carry));
-        const float alpha = 1.f - expf(-sd);
+        const float alpha = from_alpha ? sg : 1.f - expf(-sd);
         bool vis = valid && (T >= eps);
         if (alpha_thre > 0.f) vis = vis && (alpha >= alpha_thre);
         if (valid) mask[i] = vis ? 1 : 0;
@@ -190,8 +244,55 @@ extern "C" int lse_volrend_fwd(const float *t_starts, const float *t_ends, const
     LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights, "lse_volrend_fwd: null pointer");
     LSE_REQUIRE(!rgb || rgb_stride >= 3, "lse_volrend_fwd: rgb_stride < 3");
     hipLaunchKernelGGL(volrend_fwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
-                       sigmas, rgb, rgb_stride, packed_info, n_rays, weights, out_rgb, out_acc, out_depth_num);
+                       sigmas, rgb, rgb_stride, packed_info, n_rays, weights, out_rgb, out_acc, out_depth_num,
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr);
     return lse::check_launch("lse_volrend_fwd");
+}
+
+extern "C" int lse_volrend_depth_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
+                                     int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, float *weights,
+                                     float *out_rgb, float *out_acc, float *out_depth_num, float *mid_range /*[R,2]*/,
+                                     float *out_depth, float *depth_range /*[2]*/, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_volrend_depth_fwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights && out_acc && out_depth_num && mid_range && out_depth,
+                "lse_volrend_depth_fwd: null pointer");
+    LSE_REQUIRE(!rgb || rgb_stride >= 3, "lse_volrend_depth_fwd: rgb_stride < 3");
+    hipStream_t st = lse::as_stream(stream);
+    hipLaunchKernelGGL(volrend_fwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, st, t_starts, t_ends, sigmas, rgb,
+                       rgb_stride, packed_info, n_rays, weights, out_rgb, out_acc, out_depth_num, (float *)nullptr,
+                       (float *)nullptr, mid_range);
+    hipLaunchKernelGGL(depth_finish_kernel, dim3(1), dim3(1024), 0, st, out_depth_num, out_acc, mid_range, n_rays,
+                       out_depth, depth_range);
+    return lse::check_launch("lse_volrend_depth_fwd");
+}
+
+extern "C" int lse_render_weight_fwd(const float *t_starts, const float *t_ends, const float *sigmas,
+                                     const int64_t *packed_info, int32_t n_rays, float *weights, float *trans,
+                                     float *alphas, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_render_weight_fwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights, "lse_render_weight_fwd: null pointer");
+    hipLaunchKernelGGL(volrend_fwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, (const float *)nullptr, 0, packed_info, n_rays, weights, (float *)nullptr, (float *)nullptr,
+                       (float *)nullptr, trans, alphas, (float *)nullptr);
+    return lse::check_launch("lse_render_weight_fwd");
+}
+
+extern "C" int lse_render_weight_bwd(const float *t_starts, const float *t_ends, const float *sigmas,
+                                     const int64_t *packed_info, int32_t n_rays, const float *weights,
+                                     const float *d_weights, float *d_sigmas, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_render_weight_bwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights && d_weights && d_sigmas,
+                "lse_render_weight_bwd: null pointer");
+    hipLaunchKernelGGL(volrend_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, (const float *)nullptr, 0, packed_info, n_rays, weights, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, d_sigmas, (float *)nullptr, d_weights);
+    return lse::check_launch("lse_render_weight_bwd");
 }
 
 extern "C" int lse_volrend_bwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
@@ -205,7 +306,7 @@ extern "C" int lse_volrend_bwd(const float *t_starts, const float *t_ends, const
     LSE_REQUIRE(!rgb || rgb_stride >= 3, "lse_volrend_bwd: rgb_stride < 3");
     hipLaunchKernelGGL(volrend_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
                        sigmas, rgb, rgb_stride, packed_info, n_rays, weights, d_out_rgb, d_out_acc, d_out_depth_num,
-                       d_sigmas, d_rgb);
+                       d_sigmas, d_rgb, (const float *)nullptr);
     return lse::check_launch("lse_volrend_bwd");
 }
 
@@ -217,8 +318,21 @@ extern "C" int lse_visibility_mask(const float *t_starts, const float *t_ends, c
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && mask, "lse_visibility_mask: null pointer");
     hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
-                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts);
+                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts, 0);
     return lse::check_launch("lse_visibility_mask");
+}
+
+extern "C" int lse_visibility_mask_alpha(const float *alphas, const int64_t *packed_info, int32_t n_rays,
+                                         float early_stop_eps, float alpha_thre, uint8_t *mask, int64_t *new_cnts,
+                                         lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_visibility_mask_alpha: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(alphas && packed_info && mask, "lse_visibility_mask_alpha: null pointer");
+    hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream),
+                       (const float *)nullptr, (const float *)nullptr, alphas, packed_info, n_rays, early_stop_eps,
+                       alpha_thre, mask, new_cnts, 1);
+    return lse::check_launch("lse_visibility_mask_alpha");
 }
 
 extern "C" int lse_compact_samples(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info,

@@ -12,6 +12,7 @@ allocated.
 from __future__ import annotations
 
 import math
+import weakref
 from dataclasses import dataclass
 from enum import Enum
 from typing import Dict, Optional, Tuple
@@ -219,27 +220,70 @@ class LSEEmbeddingConfig:
 # ----------------------------------------------------------------------------------------------------
 # the field
 # ----------------------------------------------------------------------------------------------------
-class LSEField(nn.Module):
-    """R:lse_nerf/lse_field.py:94-360 with the default-off heads (transient/semantics/normals) omitted.
+def _contraction_mode(spatial_distortion) -> Optional[str]:
+    """Map the reference's ``spatial_distortion`` argument onto the fused position kernel's modes.
 
-    ``spatial_distortion``: ``"inf"`` (nerfstudio ``SceneContraction(order=inf)``, what R:lse_nerf/lsenerf.py:166
-    builds) or ``None`` (aabb normalisation)."""
+    Accepted: ``None`` (aabb normalisation, R:lse_nerf/lse_field.py:271), the string ``"inf"``, or any object shaped like
+    nerfstudio's ``SceneContraction`` whose ``order`` is infinity -- what R:lse_nerf/lsenerf.py:163-166 constructs.  The
+    object itself is never called: contraction + ``(x + 2) / 4`` + selector run inside ``lse_positions_fwd``."""
+    if spatial_distortion is None:
+        return None
+    if isinstance(spatial_distortion, str):
+        if spatial_distortion == "inf":
+            return "inf"
+        raise ValueError(f"spatial_distortion '{spatial_distortion}': only 'inf' (L-infinity scene contraction) is implemented")
+    order = getattr(spatial_distortion, "order", None)
+    if order is not None and float(order) == float("inf"):
+        return "inf"
+    raise NotImplementedError(
+        f"spatial_distortion {type(spatial_distortion).__name__}(order={order!r}): the HIP position kernel implements the "
+        "L-infinity SceneContraction the reference constructs (R:lse_nerf/lsenerf.py:166) and None")
+
+
+class LSEField(nn.Module):
+    """R:lse_nerf/lse_field.py:94-360: same constructor signature, buffers and methods.
+
+    ``spatial_distortion``: a nerfstudio-style ``SceneContraction(order=inf)`` object (what R:lse_nerf/lsenerf.py:166
+    builds), the string ``"inf"``, or ``None`` (aabb normalisation).  ``implementation``: ``"tcnn"`` (the reference's
+    value, R:lse_nerf/lsenerf.py:175) and ``"hip"`` both select the gfx950 kernels with tcnn's parameter layouts and
+    numerics; ``"torch"`` (nerfstudio's CPU fallback with different layouts) is the oracle's domain and raises.  The heads
+    the reference leaves switched off (transient / semantics / predicted normals) raise only when switched on."""
 
     def __init__(self, aabb: Tensor, num_images: int, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15,
                  num_levels: int = 16, base_res: int = 16, max_res: int = 2048, log2_hashmap_size: int = 19,
-                 num_layers_color: int = 3, features_per_level: int = 2, hidden_dim_color: int = 64,
-                 appearance_embedding_dim: int = 32, embd_config: Optional[LSEEmbeddingConfig] = None,
-                 spatial_distortion: Optional[str] = "inf", average_init_density: float = 1.0,
-                 implementation: str = "hip") -> None:
+                 num_layers_color: int = 3, num_layers_transient: int = 2, features_per_level: int = 2,
+                 hidden_dim_color: int = 64, hidden_dim_transient: int = 64, appearance_embedding_dim: int = 32,
+                 embd_config: Optional[LSEEmbeddingConfig] = None, transient_embedding_dim: int = 16,
+                 use_transient_embedding: bool = False, use_semantics: bool = False, num_semantic_classes: int = 100,
+                 pass_semantic_gradients: bool = False, use_pred_normals: bool = False,
+                 use_average_appearance_embedding: bool = False, spatial_distortion=None,
+                 average_init_density: float = 1.0, implementation: str = "tcnn") -> None:
         super().__init__()
+        if implementation not in ("tcnn", "hip"):
+            raise NotImplementedError(f"implementation='{implementation}': this field runs the gfx950 kernels with tcnn "
+                                      "semantics ('tcnn' / 'hip'); nerfstudio's torch fallback is restated in oracle/ only")
+        for flag, name in ((use_transient_embedding, "use_transient_embedding"), (use_semantics, "use_semantics"),
+                           (use_pred_normals, "use_pred_normals")):
+            if flag:
+                raise NotImplementedError(f"{name}=True: head not on the LSENeRF path (R:lse_nerf/lsenerf.py:168-176 leaves "
+                                          "it off); not implemented")
         assert geo_feat_dim == 15, "the fused head kernel assumes 1 + 15 base outputs"
-        assert spatial_distortion in ("inf", None)
         self.register_buffer("aabb", aabb.float())
         self.geo_feat_dim = geo_feat_dim
+        # state-dict keys of the reference (R:lse_nerf/lse_field.py:158-160)
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
         self.spatial_distortion = spatial_distortion
+        self._contraction = _contraction_mode(spatial_distortion)
         self.num_images = num_images
         self.average_init_density = average_init_density
         self.appearance_embedding_dim = appearance_embedding_dim
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        self.use_transient_embedding, self.use_semantics, self.use_pred_normals = False, False, False
+        self.pass_semantic_gradients = pass_semantic_gradients
+        self.base_res = base_res
+        self.step = 0
         if self.appearance_embedding_dim > 0:
             embd_config = embd_config or LSEEmbeddingConfig()
             self.embedding_appearance = embd_config.setup(num_imgs=num_images, num_dims=appearance_embedding_dim)
@@ -255,6 +299,7 @@ class LSEField(nn.Module):
         self.mlp_head = MLP(in_dim=16 + geo_feat_dim + self.appearance_embedding_dim, num_layers=num_layers_color,
                             layer_width=hidden_dim_color, out_dim=3, out_activation="Sigmoid")
         self._aabb6 = None
+        self._h_ref = None        # weak reference to the last base-MLP output (get_density -> get_outputs hand-over)
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _aabb_list(self):
@@ -263,7 +308,7 @@ class LSEField(nn.Module):
         return self._aabb6
 
     def _x01(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info):
-        contraction = self.spatial_distortion == "inf"
+        contraction = self._contraction == "inf"
         return ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction,
                              None if contraction else self._aabb_list())
 
@@ -333,13 +378,24 @@ class LSEField(nn.Module):
         return emb.test_emb.weight, torch.zeros(n_rays, dtype=torch.int32, device=device)
 
     # -- reference interface ---------------------------------------------------------------------------
+    @staticmethod
+    def _packed_view(ray_samples):
+        """(ray_bundle, ray_indices, packed_info) when the samples come from lsenerf_amd's VolumetricSampler (packed,
+        ray-sorted, with the owning bundle attached); (None, None, None) for a stock nerfstudio ``RaySamples``, which
+        then takes the generic per-sample path."""
+        rb = getattr(ray_samples, "ray_bundle", None)
+        ridx = getattr(ray_samples, "ray_indices", None)
+        if rb is None or ridx is None:
+            return None, None, None
+        return rb, ridx, getattr(ray_samples, "packed_info", None)
+
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         """R:lse_nerf/lse_field.py:264-288 -> (density [N,1], geo features [N,15])."""
         fr = ray_samples.frustums
-        if ray_samples.ray_indices is not None and ray_samples.ray_bundle is not None:
-            rb = ray_samples.ray_bundle
-            sigma, h, _ = self.density_packed(rb.origins, rb.directions, ray_samples.ray_indices,
-                                              fr.starts.reshape(-1), fr.ends.reshape(-1), ray_samples.packed_info)
+        rb, ridx, pinfo = self._packed_view(ray_samples)
+        if rb is not None:
+            sigma, h, _ = self.density_packed(rb.origins.contiguous(), rb.directions.contiguous(), ridx,
+                                              fr.starts.reshape(-1), fr.ends.reshape(-1), pinfo)
         else:
             pos = fr.get_positions().reshape(-1, 3).contiguous()
             sigma, h, _ = self.density_packed(pos, None, None, None, None, None)
@@ -347,8 +403,23 @@ class LSEField(nn.Module):
         shape = fr.shape
         if len(shape) != 1:
             geo = geo.reshape(*shape, self.geo_feat_dim)
-        geo._lse_full = h      # lets get_outputs feed the head from the base output without a copy
+        self._h_ref = weakref.ref(h)      # get_outputs recognises `geo` as a view of h (by storage) and skips a copy
         return sigma.view(*shape, 1), geo
+
+    def _full_base_output(self, density_embedding: Tensor, n: int) -> Tensor:
+        """The [N,16] head input.  If ``density_embedding`` is (a reshape of) the ``h[:, 1:16]`` view get_density returned,
+        h itself is used -- checked on the storage, so any copy or arithmetic on the caller's side simply falls through
+        to the padded copy below; nothing rides on Python attributes of the tensor."""
+        h = self._h_ref() if self._h_ref is not None else None
+        de = density_embedding
+        if h is not None and h.shape[0] == n and de.dtype == h.dtype and de.device == h.device \
+                and de.untyped_storage().data_ptr() == h.untyped_storage().data_ptr() \
+                and de.storage_offset() == h.storage_offset() + 1 and de.numel() == n * self.geo_feat_dim \
+                and de.stride(-1) == 1 and all(st % 16 == 0 for st in de.stride()[:-1]) \
+                and de.reshape(n, self.geo_feat_dim).stride() == (16, 1):
+            return h
+        return torch.cat([torch.zeros(n, 1, device=de.device, dtype=de.dtype), de.reshape(n, self.geo_feat_dim)],
+                         dim=1).contiguous()
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> Dict[FieldHeadNames, Tensor]:
         """R:lse_nerf/lse_field.py:290-360 -> {RGB: [N,3]}."""
@@ -356,18 +427,16 @@ class LSEField(nn.Module):
         if ray_samples.camera_indices is None:
             raise AttributeError("Camera indices are not provided.")
         fr = ray_samples.frustums
-        n = len(ray_samples)
+        n = fr.directions.reshape(-1, 3).shape[0]
         dev = fr.directions.device
-        h = getattr(density_embedding, "_lse_full", None)
-        if h is None:
-            h = torch.cat([torch.zeros(n, 1, device=dev), density_embedding.reshape(n, self.geo_feat_dim)], dim=1).contiguous()
-        if ray_samples.ray_indices is not None and ray_samples.ray_bundle is not None:
-            rb = ray_samples.ray_bundle
-            dirs, ridx, pinfo, n_rays = rb.directions, ray_samples.ray_indices, ray_samples.packed_info, len(rb)
+        h = self._full_base_output(density_embedding, n)
+        rb, ridx, pinfo = self._packed_view(ray_samples)
+        if rb is not None:
+            dirs, n_rays = rb.directions.contiguous(), len(rb)
             meta, cams = rb.metadata, rb.camera_indices
-        else:   # arbitrary per-sample directions: every sample is its own "ray"
+        else:   # stock RaySamples: arbitrary per-sample directions / ids -- every sample is its own "ray"
             dirs, ridx, pinfo, n_rays = fr.directions.reshape(-1, 3).contiguous(), None, None, n
-            meta, cams = ray_samples.metadata, ray_samples.camera_indices
+            meta, cams = (getattr(ray_samples, "metadata", None) or {}), ray_samples.camera_indices
         if self.embedding_appearance is None:
             table, eidx = None, None
         elif self.training:

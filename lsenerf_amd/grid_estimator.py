@@ -78,8 +78,6 @@ class LSEOccGridEstimator(nn.Module):
                  cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False):
         """Sampling with spatial skipping (not differentiable).  Returns (ray_indices, t_starts, t_ends); with
         ``return_packed`` also ``packed_info`` and ray_indices stays int32."""
-        if alpha_fn is not None:
-            raise NotImplementedError("alpha_fn is not on the LSENeRF path (VolumetricSampler passes sigma_fn)")
         near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
         far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
         if t_min is not None:
@@ -97,15 +95,24 @@ class LSEOccGridEstimator(nn.Module):
             self.after_march_hook()
 
         # skip invisible space
-        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None) and t_starts.shape[0] > 0:
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None) \
+                and t_starts.shape[0] > 0:
             if self._occ_mean_host is None:
                 self._occ_mean_host = self.occs.mean().item()
             alpha_thre = min(alpha_thre, self._occ_mean_host)
-            with torch.no_grad():
-                sigmas = sigma_fn(t_starts, t_ends, ray_indices)
-            assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
-            ray_indices, t_starts, t_ends, packed_info, _ = ops.visibility_compact(
-                ray_indices, t_starts, t_ends, sigmas.contiguous(), packed_info, early_stop_eps, alpha_thre)
+            if sigma_fn is not None:
+                with torch.no_grad():
+                    sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+                assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+                ray_indices, t_starts, t_ends, packed_info, _ = ops.visibility_compact(
+                    ray_indices, t_starts, t_ends, sigmas.contiguous(), packed_info, early_stop_eps, alpha_thre)
+            else:
+                with torch.no_grad():
+                    alphas = alpha_fn(t_starts, t_ends, ray_indices)
+                assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
+                ray_indices, t_starts, t_ends, packed_info, _ = ops.visibility_compact(
+                    ray_indices, t_starts, t_ends, alphas.contiguous(), packed_info, early_stop_eps, alpha_thre,
+                    from_alpha=True)
         if return_packed:
             return ray_indices, t_starts, t_ends, packed_info
         return ray_indices.long(), t_starts, t_ends

@@ -22,8 +22,8 @@ from torch import Tensor, nn
 from . import ops
 from .field import FieldHeadNames, LSEEmbeddingConfig, LSEField
 from .grid_estimator import LSEOccGridEstimator
-from .rays import Frustums, RayBundle, RaySamples
-from .renderer import AccumulationRenderer, DepthRenderer, LinearRenderer, RGBRenderer, finish_depth
+from .rays import Frustums, RayBundle, RaySamples, SceneBox, SceneContraction
+from .renderer import AccumulationRenderer, DepthRenderer, LinearRenderer, RGBRenderer
 
 EPS = 1e-6   # R:lse_nerf/utils.py:12
 
@@ -125,21 +125,37 @@ def to_gray(x: Tensor) -> Tensor:
 
 
 class VolumetricSampler(nn.Module):
-    """nerfstudio 0.3.2 ``VolumetricSampler`` (constructed at R:lse_nerf/lsenerf.py:191-194)."""
+    """nerfstudio 0.3.2 ``VolumetricSampler`` (constructed at R:lse_nerf/lsenerf.py:191-194 with
+    ``density_fn=self.field.density_fn``).
+
+    ``density_fn`` is nerfstudio's positions -> density callable.  When it is the bound ``density_fn`` of an ``LSEField``
+    the pre-pass evaluates that field on the packed samples directly (positions are formed inside ``lse_positions_fwd``
+    from per-ray origins / directions -- no [N,3] gathers); any other callable takes nerfstudio's generic route
+    (``origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends) / 2`` -> ``density_fn``)."""
 
     def __init__(self, occupancy_grid: LSEOccGridEstimator, density_fn: Optional[Callable] = None):
         super().__init__()
         assert occupancy_grid is not None
         self.density_fn = density_fn
         self.occupancy_grid = occupancy_grid
+        owner = getattr(density_fn, "__self__", None)
+        # (the field is registered on the model, not here: keep a plain reference without making it a sub-module)
+        object.__setattr__(self, "_packed_field", owner if isinstance(owner, LSEField) and
+                           getattr(density_fn, "__func__", None) is LSEField.density_fn else None)
 
-    def get_sigma_fn(self, origins, directions) -> Optional[Callable]:
+    def get_sigma_fn(self, origins, directions, times=None) -> Optional[Callable]:
         if self.density_fn is None or not self.training:
             return None
-        density_fn = self.density_fn
+        density_fn, fld = self.density_fn, self._packed_field
 
         def sigma_fn(t_starts, t_ends, ray_indices):
-            return density_fn(origins, directions, ray_indices, t_starts, t_ends)
+            if fld is not None:
+                return fld.density_packed(origins, directions, ray_indices.to(torch.int32), t_starts, t_ends, None)[0]
+            ri = ray_indices.long()
+            positions = origins[ri] + directions[ri] * (t_starts + t_ends)[:, None] / 2.0
+            if times is None:
+                return density_fn(positions).squeeze(-1)
+            return density_fn(positions, times[ri]).squeeze(-1)
         return sigma_fn
 
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
@@ -153,7 +169,8 @@ class VolumetricSampler(nn.Module):
             far_plane = 1e10
         camera_indices = ray_bundle.camera_indices
         ray_indices, starts, ends, packed_info = self.occupancy_grid.sampling(
-            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max, sigma_fn=self.get_sigma_fn(rays_o, rays_d),
+            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max,
+            sigma_fn=self.get_sigma_fn(rays_o, rays_d, ray_bundle.times),
             render_step_size=render_step_size, near_plane=near_plane, far_plane=far_plane, stratified=self.training,
             cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, return_packed=True)
         num_samples = starts.shape[0]
@@ -178,10 +195,13 @@ class VolumetricSampler(nn.Module):
 class LSENeRFModel(nn.Module):
     """R:lse_nerf/lsenerf.py:141-439 (NGPModel subclass upstream)."""
 
-    def __init__(self, config: LSENeRFModelConfig, scene_aabb: Tensor, num_train_data: int, **kwargs) -> None:
+    def __init__(self, config: LSENeRFModelConfig, scene_box, num_train_data: int, **kwargs) -> None:
+        """``scene_box``: a nerfstudio-style ``SceneBox`` (anything with ``.aabb`` [2,3]) as nerfstudio's
+        ``Model.__init__(config, scene_box, num_train_data, **kwargs)`` receives it, or the aabb tensor itself."""
         super().__init__()
         self.config = config
-        self.scene_aabb_2x3 = scene_aabb.float().reshape(2, 3)
+        self.scene_box = scene_box if hasattr(scene_box, "aabb") else SceneBox(aabb=scene_box.float().reshape(2, 3))
+        self.scene_aabb_2x3 = self.scene_box.aabb.float().reshape(2, 3)
         self.num_train_data = num_train_data
         self.kwargs = kwargs
         self.collider = None                       # enable_collider False for NGP
@@ -194,17 +214,18 @@ class LSENeRFModel(nn.Module):
     # -- R:lse_nerf/lsenerf.py:158-228 ----------------------------------------------------------------
     def populate_modules(self):
         cfg = self.config
+        scene_contraction = None if cfg.disable_scene_contraction else SceneContraction(order=float("inf"))
         self.field = LSEField(aabb=self.scene_aabb_2x3, num_images=self.num_train_data,
                               log2_hashmap_size=cfg.log2_hashmap_size, max_res=cfg.max_res,
-                              spatial_distortion=None if cfg.disable_scene_contraction else "inf",
-                              embd_config=cfg.embed_config, num_levels=cfg.num_levels, hidden_dim=cfg.hidden_dim,
+                              spatial_distortion=scene_contraction, embd_config=cfg.embed_config, implementation="tcnn",
+                              num_levels=cfg.num_levels, hidden_dim=cfg.hidden_dim,      # (field-size knobs: BASELINE config 1)
                               hidden_dim_color=cfg.hidden_dim_color)
         self.scene_aabb = nn.Parameter(self.scene_aabb_2x3.flatten(), requires_grad=False)
         if cfg.render_step_size is None:   # auto step size: ~1000 samples in the base level grid
             cfg.render_step_size = ((self.scene_aabb[3:] - self.scene_aabb[:3]) ** 2).sum().sqrt().item() / 1000
         self.occupancy_grid = LSEOccGridEstimator(roi_aabb=self.scene_aabb.data, resolution=cfg.grid_resolution,
                                                   levels=cfg.grid_levels)
-        self.sampler = VolumetricSampler(occupancy_grid=self.occupancy_grid, density_fn=self._packed_density_fn)
+        self.sampler = VolumetricSampler(occupancy_grid=self.occupancy_grid, density_fn=self.field.density_fn)
         self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
         self.renderer_accumulation = AccumulationRenderer()
         self.renderer_depth = DepthRenderer(method="expected")
@@ -223,12 +244,6 @@ class LSENeRFModel(nn.Module):
             self.rgb_to_one = ThreeToOne()
         elif cfg.ev_one_dim == "gt":
             self.rgb_to_one = ToGrayGT()
-
-    def _packed_density_fn(self, origins, directions, ray_indices, t_starts, t_ends) -> Tensor:
-        """sigma_fn of nerfstudio's VolumetricSampler: positions at the interval mid-points -> field.density_fn.
-        Evaluated on packed samples without materialising the [N,3] gathers."""
-        sigma, _, _ = self.field.density_packed(origins, directions, ray_indices, t_starts, t_ends, None)
-        return sigma
 
     def get_training_callbacks(self):
         """NGPModel.get_training_callbacks: occupancy refresh before every train iteration."""
@@ -289,13 +304,12 @@ class LSENeRFModel(nn.Module):
         linear = isinstance(self.renderer_rgb, LinearRenderer)
         if not (self.training or linear):
             rgb16 = torch.nan_to_num(rgb16)
-        rgb, acc, depth_num, weights = ops.volume_render(t_starts, t_ends, sigma, rgb16, packed_info)
+        rgb, acc, depth, weights = ops.volume_render_depth(t_starts, t_ends, sigma, rgb16, packed_info)
         bg = self.config.background_color
         if bg not in ("random", "last_sample"):
             rgb = rgb + {"black": 0.0, "white": 1.0}[bg] * (1.0 - acc[:, None])
         if not (self.training or linear):
             rgb = torch.clamp(rgb, 0.0, 1.0)
-        depth = finish_depth(depth_num, acc, t_starts, t_ends)
         return {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                 "num_samples_per_ray": packed_info[:, 1]}
 

@@ -187,8 +187,10 @@ def pack_info_from_counts(cnts: torch.Tensor):
 
 
 @torch.no_grad()
-def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float):
-    """render_visibility_from_density + mask compaction (R:lse_nerf/lse_grid_estimator.py:120-143)."""
+def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float,
+                       from_alpha: bool = False):
+    """render_visibility_from_density (or, ``from_alpha``, render_visibility_from_alpha with ``sigmas`` holding opacities)
+    + mask compaction (R:lse_nerf/lse_grid_estimator.py:120-143)."""
     R = packed_info.shape[0]
     n = t_starts.shape[0]
     dev = t_starts.device
@@ -196,9 +198,14 @@ def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early
         return ray_indices, t_starts, t_ends, packed_info, torch.empty(0, dtype=torch.uint8, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
     new_cnts = torch.empty(R, dtype=torch.int64, device=dev)
-    _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
-              _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
-              ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    if from_alpha:
+        _lib.call("lse_visibility_mask_alpha", _f32(sigmas, "alphas"), _chk(packed_info, torch.int64, "packed_info"), R,
+                  float(early_stop_eps), float(alpha_thre), ctypes.c_void_p(mask.data_ptr()),
+                  ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    else:
+        _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
+                  ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
     new_packed, total = pack_info_from_counts(new_cnts)
     m = int(total.item())
     o_ri = torch.empty(m, dtype=torch.int32, device=dev)
@@ -431,8 +438,9 @@ class _DensityFn(torch.autograd.Function):
         h, selector = ctx.saved_tensors
         n = h.shape[0]
         d_h = torch.zeros_like(h)
+        d_sigma = _c(d_sigma)     # bound to a name: stays alive until after the launch
         _lib.call("lse_density_bwd", _f32(h, "h"), _chk(selector, torch.uint8, "selector", True), float(ctx.scale),
-                  _f32(_c(d_sigma), "d_sigma"), ctypes.c_void_p(d_h.data_ptr()), n, _stream())
+                  _f32(d_sigma, "d_sigma"), ctypes.c_void_p(d_h.data_ptr()), n, _stream())
         return d_h, None, None
 
 
@@ -514,30 +522,47 @@ def linear(x, w):
 # ----------------------------------------------------------------------------------------------------
 class _VolRendFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t_starts, t_ends, sigmas, rgb, packed_info):
+    def forward(ctx, t_starts, t_ends, sigmas, rgb, packed_info, finish_depth: bool):
         R = packed_info.shape[0]
         n = t_starts.shape[0]
         dev = t_starts.device
         weights = torch.empty(n, dtype=torch.float32, device=dev)
         out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev) if rgb is not None else None
         out_acc = torch.empty(R, dtype=torch.float32, device=dev)
-        out_dep = torch.empty(R, dtype=torch.float32, device=dev)
+        out_dep = torch.empty(R, dtype=torch.float32, device=dev)      # depth numerator: sum w * (ts + te) / 2
         stride = rgb.stride(0) if rgb is not None else 0
-        _lib.call("lse_volrend_fwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
-                  _rgb_ptr(rgb), stride, _chk(packed_info, torch.int64, "packed_info"), R,
-                  ctypes.c_void_p(weights.data_ptr()), _f32(out_rgb, "out_rgb", True),
-                  ctypes.c_void_p(out_acc.data_ptr()), ctypes.c_void_p(out_dep.data_ptr()), _stream())
-        ctx.save_for_backward(t_starts, t_ends, sigmas, rgb, packed_info, weights)
+        head = (_f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"), _rgb_ptr(rgb), stride,
+                _chk(packed_info, torch.int64, "packed_info"), R, ctypes.c_void_p(weights.data_ptr()),
+                _f32(out_rgb, "out_rgb", True), ctypes.c_void_p(out_acc.data_ptr()), ctypes.c_void_p(out_dep.data_ptr()))
+        depth = rng = None
+        if finish_depth:     # DepthRenderer("expected") epilogue in the same call: one [R,2] workspace, no pass over N
+            ws = torch.empty((R, 2), dtype=torch.float32, device=dev)
+            depth = torch.empty(R, dtype=torch.float32, device=dev)
+            rng = torch.empty(2, dtype=torch.float32, device=dev)
+            _lib.call("lse_volrend_depth_fwd", *head, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(depth.data_ptr()),
+                      ctypes.c_void_p(rng.data_ptr()), _stream())
+        else:
+            _lib.call("lse_volrend_fwd", *head, _stream())
+        ctx.save_for_backward(t_starts, t_ends, sigmas, rgb, packed_info, weights, out_acc, out_dep, rng)
+        ctx.finish_depth = finish_depth
         ctx.mark_non_differentiable(weights)
         ctx.set_materialize_grads(False)     # unused outputs (accumulation / depth) arrive as None, not as zero-filled tensors
         if out_rgb is None:
             out_rgb = torch.zeros((R, 3), dtype=torch.float32, device=dev)
-        return out_rgb, out_acc, out_dep, weights
+        return out_rgb, out_acc, (depth if finish_depth else out_dep), weights
 
     @staticmethod
     def backward(ctx, g_rgb, g_acc, g_dep, _g_w):
-        t_starts, t_ends, sigmas, rgb, packed_info, weights = ctx.saved_tensors
+        t_starts, t_ends, sigmas, rgb, packed_info, weights, out_acc, out_dep, rng = ctx.saved_tensors
         R = packed_info.shape[0]
+        if ctx.finish_depth and g_dep is not None:
+            # depth = clip(num / (acc + eps), lo, hi): O(R) chain rule back to (num, acc); zero where the clip is active
+            den = out_acc + 1e-10
+            raw = out_dep / den
+            g = torch.where((raw >= rng[0]) & (raw <= rng[1]), g_dep.reshape(-1), torch.zeros_like(raw))
+            extra_acc = -g * raw / den
+            g_acc = extra_acc if g_acc is None else g_acc.reshape(-1) + extra_acc
+            g_dep = g / den
         # every packed sample belongs to exactly one ray, so the kernel writes all of d_sigma; with the compact [N, 4] colour
         # layout it also writes the pad column (one 16-B store per sample), so neither buffer needs a zero-fill
         d_sigma = torch.empty_like(sigmas)
@@ -545,13 +570,52 @@ class _VolRendFn(torch.autograd.Function):
         d_rgb = None
         if rgb is not None and ctx.needs_input_grad[3]:
             d_rgb = torch.empty_like(rgb) if (stride == 4 and rgb.is_contiguous() and rgb.data_ptr() % 16 == 0) else torch.zeros_like(rgb)
+        # contiguous copies are bound to names: a temporary freed before the launch could be re-used by the next allocation
+        g_rgb = _c(g_rgb) if g_rgb is not None else None
+        g_acc = _c(g_acc) if g_acc is not None else None
+        g_dep = _c(g_dep) if g_dep is not None else None
         _lib.call("lse_volrend_bwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
                   _rgb_ptr(rgb), stride, _chk(packed_info, torch.int64, "packed_info"), R, _f32(weights, "weights"),
-                  _f32(_c(g_rgb), "g_rgb", True) if g_rgb is not None else None,
-                  _f32(_c(g_acc), "g_acc", True) if g_acc is not None else None,
-                  _f32(_c(g_dep), "g_dep", True) if g_dep is not None else None,
+                  _f32(g_rgb, "g_rgb", True), _f32(g_acc, "g_acc", True), _f32(g_dep, "g_dep", True),
                   ctypes.c_void_p(d_sigma.data_ptr()), _rgb_ptr(d_rgb), _stream())
-        return None, None, d_sigma, d_rgb, None
+        return None, None, d_sigma, d_rgb, None, None
+
+
+class _RenderWeightFn(torch.autograd.Function):
+    """nerfacc.render_weight_from_density on packed samples (generic route: the caller composites with the weights)."""
+
+    @staticmethod
+    def forward(ctx, t_starts, t_ends, sigmas, packed_info):
+        R = packed_info.shape[0]
+        weights = torch.empty_like(sigmas)
+        trans = torch.empty_like(sigmas)
+        alphas = torch.empty_like(sigmas)
+        _lib.call("lse_render_weight_fwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _chk(packed_info, torch.int64, "packed_info"), R, ctypes.c_void_p(weights.data_ptr()),
+                  ctypes.c_void_p(trans.data_ptr()), ctypes.c_void_p(alphas.data_ptr()), _stream())
+        ctx.save_for_backward(t_starts, t_ends, sigmas, packed_info, weights)
+        ctx.mark_non_differentiable(trans, alphas)
+        return weights, trans, alphas
+
+    @staticmethod
+    def backward(ctx, g_w, _g_t, _g_a):
+        t_starts, t_ends, sigmas, packed_info, weights = ctx.saved_tensors
+        if g_w is None:
+            return None, None, None, None
+        g_w = _c(g_w)
+        d_sigma = torch.empty_like(sigmas)
+        _lib.call("lse_render_weight_bwd", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _chk(packed_info, torch.int64, "packed_info"), packed_info.shape[0], _f32(weights, "weights"),
+                  _f32(g_w, "d_weights"), ctypes.c_void_p(d_sigma.data_ptr()), _stream())
+        return None, None, d_sigma, None
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info):
+    """(weights, transmittance, alphas), each [N]; differentiable w.r.t. sigmas through the weights."""
+    if t_starts.shape[0] == 0:
+        z = torch.zeros_like(sigmas)
+        return z, z.clone(), z.clone()
+    return _RenderWeightFn.apply(_c(t_starts), _c(t_ends), _c(sigmas), packed_info)
 
 
 def _rgb_ptr(rgb):
@@ -566,7 +630,13 @@ def volume_render(t_starts, t_ends, sigmas, rgb, packed_info):
     """render_weight_from_density + accumulate_along_rays (R:lse_nerf/lsenerf.py:301-318).
     ``rgb`` may be the padded [N,16] head output (only columns 0..2 are read).
     Returns (rgb[R,3], accumulation[R], depth_numerator[R] = sum w*(ts+te)/2, weights[N])."""
-    return _VolRendFn.apply(t_starts, t_ends, sigmas, rgb, packed_info)
+    return _VolRendFn.apply(t_starts, t_ends, sigmas, rgb, packed_info, False)
+
+
+def volume_render_depth(t_starts, t_ends, sigmas, rgb, packed_info):
+    """``volume_render`` + the DepthRenderer("expected") epilogue (R:lse_nerf/lsenerf.py:315-317) in one call:
+    returns (rgb[R,3], accumulation[R], depth[R] = clip(num / (acc + 1e-10), min mid-point, max mid-point), weights[N])."""
+    return _VolRendFn.apply(t_starts, t_ends, sigmas, rgb, packed_info, True)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -4,10 +4,31 @@
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, Optional
+from typing import Dict, Optional, Union
 
 import torch
 from torch import Tensor
+
+
+class SceneContraction(torch.nn.Module):
+    """nerfstudio ``SceneContraction`` (field_components/spatial_distortions.py) as the reference builds it at
+    R:lse_nerf/lsenerf.py:163-166: ``x`` if ``|x| < 1`` else ``(2 - 1/|x|) x/|x|`` with ``|.|`` the given norm order.
+    ``LSEField`` only reads ``.order`` (the contraction itself is fused into ``lse_positions_fwd``); calling the module
+    evaluates the same map with torch ops for callers that use it directly."""
+
+    def __init__(self, order: Optional[Union[float, int]] = None) -> None:
+        super().__init__()
+        self.order = order
+
+    def forward(self, positions: Tensor) -> Tensor:
+        mag = torch.linalg.norm(positions, ord=self.order, dim=-1)[..., None]
+        return torch.where(mag < 1, positions, (2 - (1 / mag)) * (positions / mag))
+
+
+@dataclass
+class SceneBox:
+    """nerfstudio ``SceneBox``: ``aabb`` [2,3] (min corner, max corner)."""
+    aabb: Tensor
 
 
 @dataclass

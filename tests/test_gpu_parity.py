@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import TOL_GRAD_BLOCK, blockwise_nmax_err, hash_level_bounds, rel_l2  # noqa: E402
 from tests.util import TOL_FWD, TOL_GRAD, nmax_err, random_binaries, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -229,8 +230,118 @@ def test_hash_fwd_bwd(L, T):
     (y_ref * w).sum().backward()
     (y_nl * w.cuda()).sum().backward()
     assert nmax_err(tg.grad, tc.grad) < TOL_GRAD
+    # ... and level by level, each scaled by its own maximum, plus relative L2
+    assert blockwise_nmax_err(tg.grad, tc.grad, hash_level_bounds(meta)) < TOL_GRAD_BLOCK
+    assert rel_l2(tg.grad, tc.grad) < TOL_GRAD
     # d/dx: exclude points sitting on a cell boundary at some level (floor() flips are fp-order dependent)
     assert nmax_err(xg.grad[8:], xc.grad[8:]) < TOL_GRAD
+
+
+def _ray_coherent_points(n_rays, per_ray, seed, step=2 * 3 ** 0.5 / 1000 / 4):
+    """Unit-cube positions as the metric workload produces them: `per_ray` CONSECUTIVE samples of each ray at the auto step
+    size (divided by 4: the field maps [-2,2] onto [0,1]), rays through the cube in random directions."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
+    o = 0.5 - d * (step * per_ray / 2) + (torch.rand(n_rays, 3, generator=g) - 0.5) * 0.2
+    t = step * (torch.arange(per_ray, dtype=torch.float32) + 0.5)
+    x = (o[:, None, :] + d[:, None, :] * t[None, :, None]).reshape(-1, 3)
+    return x.clamp(1e-6, 1 - 1e-6).contiguous()
+
+
+def _hash_bwd_ex(ops, meta, x, dy, table, with_dx=True, **opt_kw):
+    import ctypes
+    from lsenerf_amd import _lib
+    o = _lib.hash_bwd_default_opts()
+    for k, v in opt_kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    dt = torch.zeros_like(table)
+    dx = torch.empty_like(x) if with_dx else None
+    desc = meta.desc()
+    P = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
+    _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x), P(dy), P(table), P(dt), P(dx), 0, 0, meta.n_levels, x.shape[0],
+              ctypes.byref(o), ops._stream())
+    return dt, dx
+
+
+def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
+    """The regime bench.py times: 64 rays x 1024 CONSECUTIVE samples each (16 waves per ray, runs of many lanes per cell on
+    the coarse levels, ~2 cells per step on the finest), L = 16, T = 2^19.  The default kernel (run scan, cross-row carry,
+    LDS sector cache, few-runs path, pair-lane collision atomics), its 64-B-line and second-probe variants and the
+    16-lanes-per-sample kernel are selected through lse_hash_bwd_ex's CALL ARGUMENTS in one process and all compared with
+    oracle/hashgrid.py, level by level."""
+    from oracle import hashgrid as ohg
+    ops = _ops()
+    meta_o = ohg.tcnn_grid_meta(n_levels=16, log2_hashmap_size=19)
+    meta = ops.make_grid_meta(n_levels=16, log2_hashmap_size=19)
+    x = _ray_coherent_points(64, 1024, seed=3)
+    N = x.shape[0]
+    g = torch.Generator().manual_seed(4)
+    table = (torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.1
+    w = torch.randn(N, 32, generator=g)
+    tc, xc = table.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    (ohg.hash_encode_tcnn(xc, tc, meta_o) * w).sum().backward()
+    dy = w.reshape(N, 16, 2).permute(1, 0, 2).contiguous().cuda()          # level-major, as the fused MLP hands it over
+    xg, tg = x.cuda(), table.cuda()
+    bounds = hash_level_bounds(meta)
+    variants = {"default": {}, "line_cache": {"gran": 3}, "second_probe": {"second_probe": 1}, "no_few_runs": {"few_runs": 0},
+                "lanes16": {"impl": 0}, "lanes16_r64": {"impl": 0, "rounds": 64}}
+    # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
+    on_face = torch.zeros(N, dtype=torch.bool)
+    for sc in meta.scales:
+        p = x.double() * sc + 0.5
+        on_face |= ((p - p.round()).abs() < 1e-4).any(-1)
+    for name, kw in variants.items():
+        dt, dx = _hash_bwd_ex(ops, meta, xg, dy, tg, **kw)
+        assert nmax_err(dt, tc.grad) < TOL_GRAD, name
+        blk = blockwise_nmax_err(dt, tc.grad, bounds)
+        assert blk < TOL_GRAD_BLOCK, (name, blk)
+        assert rel_l2(dt, tc.grad) < TOL_GRAD, name
+        assert nmax_err(dx.cpu()[~on_face], xc.grad[~on_face]) < TOL_GRAD, name
+
+
+def test_hash_full_size_forward_subset_and_backward_linearity():
+    """BASELINE size: N = 2^22 ray-coherent samples, T = 2^19.  The oracle evaluates a 2^16-sample random subset of the
+    forward and of d(x); the table gradient is checked through linearity of the encoding in the table:
+    <dtable, dt> == <dy, encode(x; dt)> for random dt (fp64 inner products), level by level."""
+    from oracle import hashgrid as ohg
+    ops = _ops()
+    meta_o = ohg.tcnn_grid_meta(n_levels=16, log2_hashmap_size=19)
+    meta = ops.make_grid_meta(n_levels=16, log2_hashmap_size=19)
+    x = _ray_coherent_points(4096, 1024, seed=7).cuda()
+    N = x.shape[0]
+    assert N == 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(8)
+    table = (torch.rand(meta.n_params, generator=g, device="cuda") * 2 - 1) * 0.1
+    y = ops.hash_encode(x, table, meta)                                   # [16, N, 2]
+    sub = torch.randperm(N, generator=torch.Generator().manual_seed(9))[: 1 << 16]
+    xs = x[sub.cuda()].cpu().requires_grad_(True)
+    tcpu = table.cpu()
+    y_ref = ohg.hash_encode_tcnn(xs, tcpu, meta_o)
+    y_sub = y[:, sub.cuda(), :].permute(1, 0, 2).reshape(len(sub), -1)
+    assert nmax_err(y_sub, y_ref) < TOL_FWD
+    for l in range(16):                                                   # every level separately: coarse ones are 100x larger
+        assert nmax_err(y_sub[:, 2 * l:2 * l + 2], y_ref[:, 2 * l:2 * l + 2]) < TOL_FWD, l
+    dy = torch.randn(16, N, 2, generator=g, device="cuda")
+    dt, dx = _hash_bwd_ex(ops, meta, x, dy, table)
+    # d(x) on the subset against the oracle (a sample's d(x) depends on that sample only)
+    w_sub = dy[:, sub.cuda(), :].permute(1, 0, 2).reshape(len(sub), -1).cpu()
+    (y_ref * w_sub).sum().backward()
+    on_face = torch.zeros(len(sub), dtype=torch.bool)
+    for sc in meta.scales:
+        p = xs.detach().double() * sc + 0.5
+        on_face |= ((p - p.round()).abs() < 1e-4).any(-1)
+    assert nmax_err(dx[sub.cuda()].cpu()[~on_face], xs.grad[~on_face]) < TOL_GRAD
+    # table gradient: adjoint identity, per level (J is block diagonal over levels)
+    bounds = hash_level_bounds(meta)
+    for trial in range(2):
+        dtab = torch.randn(meta.n_params, generator=g, device="cuda")
+        jd = ops.hash_encode(x, dtab, meta)                               # J dt, level-major
+        for l in range(16):
+            lhs = float((dt[bounds[l]:bounds[l + 1]].double() * dtab[bounds[l]:bounds[l + 1]].double()).sum())
+            rhs = float((dy[l].double() * jd[l].double()).sum())
+            scale = float(dt[bounds[l]:bounds[l + 1]].double().norm() * dtab[bounds[l]:bounds[l + 1]].double().norm())
+            assert abs(lhs - rhs) <= 1e-5 * scale, (trial, l, lhs, rhs, scale)
 
 
 def test_hash_bwd_level_ranges_add_up():

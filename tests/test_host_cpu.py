@@ -25,8 +25,29 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
-    assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error"} == set(names)
-    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 1
+    assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts"} == set(names)
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 2
+
+
+def test_runtime_options_and_hash_bwd_opts_without_gpu():
+    """Tuning knobs are call arguments (lse_hash_bwd_ex) or run-time options -- no process-lifetime environment statics."""
+    from lsenerf_amd import _lib
+    o = _lib.hash_bwd_default_opts()
+    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg) == (1, 2, 6, 0, 32, 0)
+    assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28
+    _lib.set_option("mlp_fwd_cfg", 44)
+    assert _lib.get_option("mlp_fwd_cfg") == 44
+    _lib.set_option("mlp_fwd_cfg", 28)
+    with pytest.raises(_lib.LseHipError):
+        _lib.set_option("no_such_option", 1)
+    # invalid kernel selections are rejected before anything is launched
+    import ctypes
+    d = _lib.GridDesc()
+    d.n_levels, d.n_features = 1, 2
+    d.offsets[0], d.offsets[1], d.scales[0], d.resolutions[0] = 0, 8, 1.0, 2
+    o.impl = 7
+    with pytest.raises(_lib.LseHipError):
+        _lib.call("lse_hash_bwd_ex", ctypes.byref(d), None, None, None, None, None, 0, 0, 1, 0, ctypes.byref(o), None)
 
 
 def test_argument_counts_match_header():

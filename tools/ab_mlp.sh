@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B the MLP kernel configurations (CT*10+NW): correctness (pytest -k mlp) then per-step kernel times from bench.py
 for cfg in 44 28; do
-  export LSE_MLP_FWD_CFG=$cfg LSE_MLP_BWD_CFG=$cfg
+  export LSE_OPT_MLP_FWD_CFG=$cfg LSE_OPT_MLP_BWD_CFG=$cfg
   r=$(timeout -k 10 200 python -m pytest tests -m gpu -q -k "mlp or config1" 2>&1 | tail -1)
   b=$(timeout -k 10 200 python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('ms/step %.2f fwd %.3f bwd %.3f' % (d['ms_per_step'], k['lse_mlp_fwd'], k['lse_mlp_bwd']))")
   echo "cfg=$cfg | $r | $b"
