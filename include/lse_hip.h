@@ -255,6 +255,41 @@ int lse_occ_update_cells(float *occs, const int64_t *cell_ids, const float *occ_
                          float *workspace, lse_stream_t stream);
 int lse_occ_binarize(const float *occs, int64_t n, const float *d_threshold, uint8_t *binaries, lse_stream_t stream);
 
+/* ---- training epilogue: output routing + intensity mappers + both losses, O(rays), one launch each way
+ *      (R:lse_nerf/lsenerf.py:329-377 routing, :392-439 losses; R:lse_nerf/intensity_mappers.py:64-94 mappers).
+ * Colour bundle:  v = rgb_mapped ? m_rgb(max(rgb, 1e-5)) : rgb;  mean over deblur_group consecutive rays (the 4 virtual
+ *   cameras of a pixel, R:lse_nerf/lsenerf.py:365-370);  max(., 1e-5);  rgb_loss = mean (v - col_gt)^2.
+ * Event bundles (prev, next):  c = max(rgb, 1e-5);  ev_one_dim != NONE: m_evs(sum_k w_k c_k) with w = softmax(w31)
+ *   (ThreeToOne, LEARNED) or the gray vector (GRAY);  NONE: gray(m_evs(c));  L = log(. + 1e-6);
+ *   event_loss = evs_loss_weight * mean (L_next - L_prev - evs_gt)^2          (log_loss).
+ * m = identity | x^(1/2.4) ("gt") | x^p ("powpow", p = *pow_rgb / *pow_evs, learnable). */
+#define LSE_MAP_IDENTITY 1
+#define LSE_MAP_GT 2
+#define LSE_MAP_POWPOW 3
+#define LSE_ONE_DIM_NONE 0
+#define LSE_ONE_DIM_LEARNED 1
+#define LSE_ONE_DIM_GRAY 2
+typedef struct lse_epilogue_desc {
+    int32_t rgb_mapped;      /* 0: the colour loss sees the raw render; 1: m_rgb(max(rgb, 1e-5)) */
+    int32_t rgb_mapper;      /* LSE_MAP_* */
+    int32_t evs_mapper;      /* LSE_MAP_* applied on the event side */
+    int32_t ev_one_dim;      /* LSE_ONE_DIM_* */
+    int32_t deblur_group;    /* 1, or 4 for rgb_loss_type == "deblur" */
+    float evs_loss_weight;
+} lse_epilogue_desc;
+/* losses[2] = (rgb_loss, event_loss); a bundle whose pointer is NULL contributes 0.  Deterministic (no atomics). */
+int lse_loss_epilogue_fwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
+                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
+                          const float *pow_rgb, const float *pow_evs, const float *w31, float *losses,
+                          lse_stream_t stream);
+/* g_rgb_loss / g_event_loss: device scalars, the upstream gradients of the two losses (NULL = 0).  d_col [n_col*deblur_group,3], d_prev / d_next [n_ev,3]
+ * (each nullable) are overwritten; d_scalars[5] = (d pow_rgb, d pow_evs, d w31[3]) is overwritten. */
+int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
+                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
+                          const float *pow_rgb, const float *pow_evs, const float *w31, const float *g_rgb_loss,
+                          const float *g_event_loss, float *d_col, float *d_prev, float *d_next, float *d_scalars,
+                          lse_stream_t stream);
+
 /* ---- optimiser: torch.optim.Adam semantics on a flat buffer (R:lse_nerf/lse_config.py:29-33) ----------- */
 int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream);

@@ -29,6 +29,15 @@ class HashBwdOpts(Structure):
                 ("dbg", c_int32), ("interleave_from_scale", c_float)]
 
 
+class EpilogueDesc(Structure):
+    _fields_ = [("rgb_mapped", c_int32), ("rgb_mapper", c_int32), ("evs_mapper", c_int32), ("ev_one_dim", c_int32),
+                ("deblur_group", c_int32), ("evs_loss_weight", c_float)]
+
+
+LSE_MAP_IDENTITY, LSE_MAP_GT, LSE_MAP_POWPOW = 1, 2, 3
+LSE_ONE_DIM_NONE, LSE_ONE_DIM_LEARNED, LSE_ONE_DIM_GRAY = 0, 1, 2
+
+
 class MlpDesc(Structure):
     _fields_ = [("n_in", c_int32), ("width", c_int32), ("n_hidden_layers", c_int32), ("out_activation", c_int32),
                 ("in_layout", c_int32)]
@@ -71,6 +80,8 @@ SIGNATURES = {
     "lse_volrend_depth_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P, P],
     "lse_render_weight_fwd": [P, P, P, P, I32, P, P, P, P],
     "lse_render_weight_bwd": [P, P, P, P, I32, P, P, P, P],
+    "lse_loss_epilogue_fwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, P, P],
+    "lse_loss_epilogue_bwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, P, P, P, P, P, P, P],
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],

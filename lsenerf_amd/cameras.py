@@ -62,6 +62,27 @@ def exp_map_SO3xR3(tangent_vector: Tensor) -> Tensor:
     return hom_exp_map_SO3xR3(tangent_vector)[:, :3, :4]
 
 
+def exp_map_SE3(tangent_vector: Tensor) -> Tensor:
+    """SE(3) exponential: tangent [N,6] = (v, omega) -> [N,3,4] = [exp(omega^) | V v] with
+    V = I + (1 - cos t)/t^2 omega^ + (t - sin t)/t^3 omega^2, t = |omega| (Taylor series below t = 1e-2).  What the reference's
+    ``mode="SE3"`` evaluates through nerfstudio's lie_groups (R:lse_nerf/ns_camera_optimizer.py:276-277); checked against
+    scipy.linalg.expm of the 4x4 twist in tests/test_cameras_cpu.py."""
+    v, w = tangent_vector[:, :3], tangent_vector[:, 3:]
+    t2 = (w * w).sum(-1)
+    t = t2.sqrt()
+    small = t < 1e-2
+    ts = torch.where(small, torch.ones_like(t), t)            # safe denominators
+    a = torch.where(small, 1 - t2 / 6, ts.sin() / ts)                          # sin t / t
+    b = torch.where(small, 0.5 - t2 / 24, (1 - ts.cos()) / (ts * ts))          # (1 - cos t) / t^2
+    c = torch.where(small, 1.0 / 6 - t2 / 120, (ts - ts.sin()) / (ts * ts * ts))   # (t - sin t) / t^3
+    W = _hat(w)
+    W2 = W @ W
+    eye = torch.eye(3, dtype=w.dtype, device=w.device)[None]
+    R = eye + a[:, None, None] * W + b[:, None, None] * W2
+    V = eye + b[:, None, None] * W + c[:, None, None] * W2
+    return torch.cat([R, V @ v[:, :, None]], dim=-1)
+
+
 def matrix_to_tangent_vector(matrix: Tensor) -> Tensor:
     """4x4 (or 3x4) pose -> 6-vector (translation, axis*angle).  R:lse_nerf/interpolation_utils.py:14-53."""
     R = matrix[:3, :3]
@@ -211,7 +232,7 @@ class CameraOptimizerConfig:
     mode: str = "off"                 # "off" | "SO3xR3" | "SE3"
     trans_l2_penalty: float = 1e-2
     rot_l2_penalty: float = 1e-3
-    optim_type: str = "ns"            # "ns" | "spline"
+    optim_type: str = "ns"            # "ns" | "spline" | "prevnext"
     control_pnt_factor: int = 1
     scheme: str = "active"            # "active" | "delayed"
     delay_cnt: int = 10000
@@ -223,7 +244,8 @@ class CameraOptimizerConfig:
             self.delay_cnt = 1999999999
 
     def setup(self, **kwargs):
-        return {"ns": CameraOptimizer, "spline": SplineCameraOptimizer}[self.optim_type](self, **kwargs)
+        return {"ns": CameraOptimizer, "spline": SplineCameraOptimizer,
+                "prevnext": PrevNextCamOptimizer}[self.optim_type](self, **kwargs)       # R:ns_camera_optimizer.py:416-418
 
 
 class _DelayedMode:
@@ -251,9 +273,7 @@ class CameraOptimizer(nn.Module, _DelayedMode):
         super().__init__()
         self.config, self.num_cameras, self.device = config, num_cameras, device
         self.non_trainable_camera_indices = non_trainable_camera_indices
-        if config.mode == "SE3":
-            raise NotImplementedError("SE3 mode is not used by any LSENeRF preset (SO3xR3 is)")
-        if config.mode == "SO3xR3":
+        if config.mode in ("SO3xR3", "SE3"):
             self.pose_adjustment = nn.Parameter(torch.zeros((num_cameras, 6), device=device))
         else:
             assert config.mode == "off", config.mode
@@ -263,7 +283,8 @@ class CameraOptimizer(nn.Module, _DelayedMode):
         """-> [len(indices),3,4] transforms from optimised to given camera coordinates (identity when off)."""
         if self.config.mode == "off":
             return torch.eye(4, device=self.device)[None, :3, :4].tile(indices.shape[0], 1, 1)
-        out = exp_map_SO3xR3(self.pose_adjustment[indices, :])
+        exp_map = exp_map_SE3 if self.config.mode == "SE3" else exp_map_SO3xR3
+        out = exp_map(self.pose_adjustment[indices, :])
         if self.non_trainable_camera_indices is not None:
             frozen = torch.isin(indices.to(out.device), self.non_trainable_camera_indices.to(out.device))
             out = torch.where(frozen[:, None, None], torch.eye(4, device=out.device)[:3, :4].expand_as(out), out)
@@ -299,6 +320,50 @@ class CameraOptimizer(nn.Module, _DelayedMode):
             param_groups[f"{prefix}camera_opt"] = params
         else:
             assert len(params) == 0
+
+
+class PrevNextCamOptimizer(nn.Module):
+    """Two independent per-camera optimisers for the previous / next event-camera poses; ``apply_to_raybundle`` alternates
+    between them call by call (the data manager corrects the prev bundle first, then the next one).
+    R:lse_nerf/ns_camera_optimizer.py:368-414."""
+
+    def __init__(self, config: CameraOptimizerConfig, num_cameras: int, device="cpu",
+                 non_trainable_camera_indices: Optional[Tensor] = None, **kwargs) -> None:
+        super().__init__()
+        import copy
+        # (the reference shares ONE config object between the two, so the delayed scheme's first constructor call already
+        #  switches the shared mode to "off" and the second optimiser would be built without parameters; a copy per
+        #  optimiser keeps both trainable, which is what the two param groups at :410-414 expect)
+        self.prev_optim = CameraOptimizer(copy.copy(config), num_cameras, device, non_trainable_camera_indices, **kwargs)
+        self.next_optim = CameraOptimizer(copy.copy(config), num_cameras, device, non_trainable_camera_indices, **kwargs)
+        self.cnt_call = 0
+
+    def turn_on(self):
+        self.prev_optim.turn_on()
+        self.next_optim.turn_on()
+
+    def update_mode(self, step):
+        self.prev_optim.update_mode(step)
+        self.next_optim.update_mode(step)
+
+    def forward(self, indices):
+        assert 0, "not implemented"          # same behaviour as the reference (:389-390)
+
+    def apply_to_raybundle(self, raybundle: RayBundle):
+        (self.prev_optim if self.cnt_call % 2 == 0 else self.next_optim).apply_to_raybundle(raybundle)
+        self.cnt_call = (self.cnt_call + 1) % 2
+
+    def get_loss_dict(self, loss_dict):
+        self.prev_optim.get_loss_dict(loss_dict, "prev_")
+        self.next_optim.get_loss_dict(loss_dict, "next_")
+
+    def get_metrics_dict(self, metrics_dict):
+        self.prev_optim.get_metrics_dict(metrics_dict, "prev_")
+        self.next_optim.get_metrics_dict(metrics_dict, "next_")
+
+    def get_param_groups(self, param_groups):
+        self.prev_optim.get_param_groups(param_groups, "prev_")
+        self.next_optim.get_param_groups(param_groups, "next_")
 
 
 class SplineCameraOptimizer(nn.Module, _DelayedMode):
@@ -392,3 +457,60 @@ def generate_deblur_rays(cameras: EdCameras, spline: SplineCameraOptimizer, came
     finally:
         cameras.get_c2w_fn = old
     return rb
+
+
+# ----------------------------------------------------------------------------------------------------
+# ray generators (R:lse_nerf/lse_ray_generator.py; nerfstudio ``RayGenerator`` base restated)
+# ----------------------------------------------------------------------------------------------------
+class RayGenerator(nn.Module):
+    """nerfstudio ``RayGenerator``: pixel indices ``[num_rays, 3] = (camera, row, col)`` -> ``RayBundle`` through the
+    cameras and the pose optimiser (``pose_optimizer(camera_indices) -> [R,3,4]`` or ``None``)."""
+
+    def __init__(self, cameras: EdCameras, pose_optimizer: Callable = lambda x: None) -> None:
+        super().__init__()
+        self.cameras = cameras
+        self.pose_optimizer = pose_optimizer
+        self.register_buffer("image_coords", cameras.get_image_coords(), persistent=False)
+
+    def _split(self, ray_indices: Tensor):
+        c, y, x = ray_indices[:, 0], ray_indices[:, 1], ray_indices[:, 2]
+        return c, self.image_coords[y, x]
+
+    def forward(self, ray_indices: Tensor) -> RayBundle:
+        c, coords = self._split(ray_indices)
+        return self.cameras.generate_rays(camera_indices=c.unsqueeze(-1), coords=coords,
+                                          camera_opt_to_camera=self.pose_optimizer(c))
+
+
+class ConsecRayGenerator(RayGenerator):
+    """Event pixels seen from camera ``c`` and from the consecutive camera ``c + 1`` (R:lse_nerf/lse_ray_generator.py:36-68)."""
+
+    def forward(self, ray_indices: Tensor) -> Tuple[RayBundle, RayBundle]:
+        c, coords = self._split(ray_indices)
+        ray_bundle_prev = self.cameras.generate_rays(camera_indices=c.unsqueeze(-1), coords=coords)
+        ray_bundle_next = self.cameras.generate_rays(camera_indices=c.unsqueeze(-1) + 1, coords=coords)
+        return ray_bundle_prev, ray_bundle_next
+
+
+class PrevNextRayGenerator(RayGenerator):
+    """The same pixels through two camera sets: poses at the start and at the end of every event window
+    (R:lse_nerf/lse_ray_generator.py:71-100).  No pose optimiser here: PrevNextCamOptimizer corrects the bundles."""
+
+    def __init__(self, prev_cameras: EdCameras, next_cameras: EdCameras, pose_optimizer: Callable = lambda x: None) -> None:
+        super().__init__(prev_cameras, lambda x: None)
+        self.prev_cameras, self.next_cameras = prev_cameras, next_cameras
+
+    def forward(self, ray_indices: Tensor) -> Tuple[RayBundle, RayBundle]:
+        c, coords = self._split(ray_indices)
+        ray_bundle_prev = self.prev_cameras.generate_rays(camera_indices=c.unsqueeze(-1), coords=coords)
+        ray_bundle_next = self.next_cameras.generate_rays(camera_indices=c.unsqueeze(-1), coords=coords)
+        return ray_bundle_prev, ray_bundle_next
+
+
+class DeblurRayGenerator(RayGenerator):
+    """Every sampled pixel -> 4 rays from 4 virtual cameras across the exposure (R:lse_nerf/lse_ray_generator.py:103-147)."""
+
+    def forward(self, ray_indices: Tensor) -> RayBundle:
+        assert self.cameras.interpolator is not None, "requires interpolator!!"
+        c, coords = self._split(ray_indices)
+        return generate_deblur_rays(self.cameras, self.cameras.interpolator, c, coords)

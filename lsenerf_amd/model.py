@@ -313,76 +313,127 @@ class LSENeRFModel(nn.Module):
         return {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                 "num_samples_per_ray": packed_info[:, 1]}
 
-    # -- R:lse_nerf/lsenerf.py:329-377 ----------------------------------------------------------------
+    # -- output routing and losses (what R:lse_nerf/lsenerf.py:329-439 computes) ---------------------------------
+    # One description of the routing (``_plan``) drives both implementations: ``route_outputs`` / ``get_loss_dict`` build
+    # the reference's output dictionaries with torch ops (evaluation, logging, any mapper module), ``fused_loss_dict``
+    # hands the same plan to the O(R) epilogue kernel pair (lse_loss_epilogue_fwd / _bwd) for the training step.
+    def _plan(self) -> Dict[str, object]:
+        cfg = self.config
+        mode = cfg.map_mode if (cfg.use_mapping or cfg.map_mode == "rgb_evs") else None
+        one_dim = getattr(self, "rgb_to_one", None) if cfg.ev_one_dim else None
+        if cfg.use_mapping:        # the event loss reads "ev_out"
+            ev_mapper = {"co_map": self.evs_mapper, "evs_rgb": None, "rgb_evs": getattr(self, "rgb_mapper", None)}[cfg.map_mode]
+            ev_one_dim = one_dim
+        else:                      # ... otherwise the routed "rgb"
+            ev_mapper, ev_one_dim = None, None
+        return {"mode": mode, "rgb_mapper": getattr(self, "rgb_mapper", None) if mode in ("evs_rgb", "co_map") else None,
+                "ev_key": "ev_out" if cfg.use_mapping else "rgb", "ev_mapper": ev_mapper, "ev_one_dim": ev_one_dim,
+                "deblur_group": 4 if cfg.rgb_loss_type == "deblur" else 1}
+
     def get_outputs(self, ray_bundle: RayBundle, ev_out=False, jitter: Optional[Tensor] = None, **kwargs):
-        out_dict = self.exec_get_outputs(ray_bundle, jitter=jitter)
-        return self.route_outputs(out_dict, ray_bundle, ev_out=ev_out, **kwargs)
+        return self.route_outputs(self.exec_get_outputs(ray_bundle, jitter=jitter), ray_bundle, ev_out=ev_out, **kwargs)
 
     def route_outputs(self, out_dict: Dict[str, Tensor], ray_bundle: RayBundle, ev_out=False, **kwargs):
-        """The mapper routing of R:lse_nerf/lsenerf.py:333-377, applied to the hot path's outputs."""
-        cfg = self.config
-        clamp_out = torch.clamp(out_dict["rgb"], 1e-5)
-        if cfg.use_mapping or cfg.map_mode == "rgb_evs":
-            if cfg.map_mode == "rgb_evs":
-                if ev_out or not self.training:
-                    out_dict["ev_out"] = self.rgb_mapper(self.correct_evs_dim(clamp_out))
-                    out_dict["linear"] = format_linear(out_dict["ev_out"])
-            elif cfg.map_mode == "evs_rgb":
-                out_dict["ev_out"] = self.correct_evs_dim(clamp_out)
-                out_dict["linear"] = clamp_out
-                out_dict["rgb"] = self.rgb_mapper(out_dict["linear"]).to(out_dict["linear"])
-            elif cfg.map_mode == "co_map":
-                out_dict["rgb"] = self.rgb_mapper(clamp_out)
-                if ev_out or not self.training:
-                    ev_linear = self.correct_evs_dim(clamp_out)
-                    out_dict["linear"] = clamp_out
-                    out_dict["ev_linear"] = ev_linear
-                    out_dict["ev_out"] = self.evs_mapper(ev_linear, raybd1=ray_bundle, **kwargs)
-        if cfg.rgb_loss_type == "deblur" and self.training:
-            try:
-                out_dict["rgb"] = out_dict["rgb"].reshape(-1, 4, 3).mean(axis=1)
-            except Exception:
-                pass
-        if not self.training:
-            out_dict["rgb"] = torch.clamp(out_dict["rgb"], 0, 1)
-        else:
-            out_dict["rgb"] = torch.clamp(out_dict["rgb"], 1e-5)
-        return out_dict
+        """Rendered radiance -> the reference's output keys: "rgb" in display space, "linear" / "ev_linear" / "ev_out" on
+        the event side, by map_mode ("rgb_evs": render -> rgb -> events; "evs_rgb": render -> events -> rgb; "co_map":
+        one linear render feeding an rgb mapper and an event mapper)."""
+        plan, training = self._plan(), self.training
+        radiance = out_dict["rgb"]
+        linear = radiance.clamp_min(1e-5)
+        events_wanted = ev_out or not training
+        routed = dict(out_dict)
+        if plan["mode"] == "rgb_evs":
+            if events_wanted:
+                routed["ev_out"] = self.rgb_mapper(self.correct_evs_dim(linear))
+                routed["linear"] = format_linear(routed["ev_out"])
+        elif plan["mode"] == "evs_rgb":
+            routed.update(ev_out=self.correct_evs_dim(linear), linear=linear, rgb=self.rgb_mapper(linear).to(linear))
+        elif plan["mode"] == "co_map":
+            routed["rgb"] = self.rgb_mapper(linear)
+            if events_wanted:
+                ev_linear = self.correct_evs_dim(linear)
+                routed.update(linear=linear, ev_linear=ev_linear,
+                              ev_out=self.evs_mapper(ev_linear, raybd1=ray_bundle, **kwargs))
+        rgb = routed["rgb"]
+        if training and plan["deblur_group"] > 1 and rgb.shape[-1] == 3 and rgb.shape[0] % plan["deblur_group"] == 0:
+            rgb = rgb.reshape(-1, plan["deblur_group"], 3).mean(dim=1)          # the virtual cameras of one pixel
+        routed["rgb"] = rgb.clamp_min(1e-5) if training else rgb.clamp(0, 1)
+        return routed
 
-    # -- losses, R:lse_nerf/lsenerf.py:392-439 ---------------------------------------------------------
-    def log_loss(self, evs, prev_rad, next_rad, evs_batch: dict):
+    # -- losses ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _log_intensity_change(prev_rad: Tensor, next_rad: Tensor) -> Tensor:
         if prev_rad.shape[-1] != 1:
             prev_rad, next_rad = to_gray(prev_rad), to_gray(next_rad)
-        prev_log, next_log = torch.log(prev_rad + EPS), torch.log(next_rad + EPS)
-        return self.rgb_loss(next_log - prev_log, evs)
+        return torch.log(next_rad + EPS) - torch.log(prev_rad + EPS)
+
+    def log_loss(self, evs, prev_rad, next_rad, evs_batch: dict):
+        return self.rgb_loss(self._log_intensity_change(prev_rad, next_rad), evs)
 
     def mse_loss(self, rgb_gt, rgb_pred, rgb_out_dic=None):
         return self.rgb_loss(rgb_gt, rgb_pred)
 
     def enerf_norm_loss(self, evs, prev_rad, next_rad, evs_batch: dict):
-        if prev_rad.shape[-1] != 1:
-            prev_rad, next_rad = to_gray(prev_rad), to_gray(next_rad)
-        prev_log, next_log = torch.log(prev_rad + EPS), torch.log(next_rad + EPS)
-        delta_log = next_log - prev_log
-        log_norm_cnst = torch.linalg.norm(delta_log, dim=0, keepdim=True) + EPS
+        delta = self._log_intensity_change(prev_rad, next_rad)
+        delta = delta / (torch.linalg.norm(delta, dim=0, keepdim=True) + EPS)
         with torch.no_grad():
             evs = evs / evs_batch["e_thresh"]
-            evs_norm_cnst = torch.linalg.norm(evs, dim=0, keepdim=True) + EPS
-        return self.rgb_loss(delta_log / log_norm_cnst, evs / evs_norm_cnst)
+            evs = evs / (torch.linalg.norm(evs, dim=0, keepdim=True) + EPS)
+        return self.rgb_loss(delta, evs)
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
-        loss_dict = {}
-        if (batch.get("col_batch") is None) and (batch.get("evs_batch") is None):
-            loss_dict["rgb_loss"] = self.rgb_loss(batch["image"], outputs["rgb"])
-            return loss_dict
-        col_batch, evs_batch = batch["col_batch"], batch["evs_batch"]
-        col_out, prev_out, next_out = [outputs[e] for e in ["col_out", "prev_out", "next_out"]]
-        if col_out is not None:
-            loss_dict["rgb_loss"] = self.rgb_loss_fn(col_batch["image"], col_out["rgb"], col_out)
-        if prev_out is not None:
-            ev_key = "rgb" if not self.config.use_mapping else "ev_out"
-            prev_in, next_in = prev_out[ev_key], next_out[ev_key]
-            evs = evs_batch["image"]
-            evs = evs if prev_in.shape[-1] == 1 else torch.concatenate([evs] * 3, dim=-1)
-            loss_dict["event_loss"] = self.config.evs_loss_weight * self.event_loss(evs, prev_in, next_in, evs_batch)
-        return loss_dict
+        """``outputs``: {"col_out", "prev_out", "next_out"} routed dictionaries (or a plain {"rgb"} for an rgb-only batch)."""
+        if batch.get("col_batch") is None and batch.get("evs_batch") is None:
+            return {"rgb_loss": self.rgb_loss(batch["image"], outputs["rgb"])}
+        losses = {}
+        if outputs["col_out"] is not None:
+            losses["rgb_loss"] = self.rgb_loss_fn(batch["col_batch"]["image"], outputs["col_out"]["rgb"], outputs["col_out"])
+        if outputs["prev_out"] is not None:
+            key = self._plan()["ev_key"]
+            prev_in, next_in = outputs["prev_out"][key], outputs["next_out"][key]
+            evs = batch["evs_batch"]["image"]
+            if prev_in.shape[-1] != 1:
+                evs = torch.cat([evs] * 3, dim=-1)
+            losses["event_loss"] = self.config.evs_loss_weight * self.event_loss(evs, prev_in, next_in, batch["evs_batch"])
+        return losses
+
+    # -- fused training epilogue -----------------------------------------------------------------------------
+    def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor]]]:
+        """(descriptor fields, pow_rgb, pow_evs, w31) for ops.loss_epilogue, or None when the configuration needs the torch
+        route (MLP mappers, enerf_norm_loss, or the event loss reading a deblur-averaged "rgb")."""
+        from . import _lib
+        cfg, plan = self.config, self._plan()
+        kinds = {IdentityMapper: _lib.LSE_MAP_IDENTITY, GT_Mapper: _lib.LSE_MAP_GT, Powpow: _lib.LSE_MAP_POWPOW,
+                 type(None): _lib.LSE_MAP_IDENTITY}
+        if cfg.event_loss_type.lower() != "log_loss" or type(plan["rgb_mapper"]) not in kinds \
+                or type(plan["ev_mapper"]) not in kinds or (plan["ev_key"] == "rgb" and plan["deblur_group"] > 1):
+            return None
+        od = plan["ev_one_dim"]
+        one_dim = _lib.LSE_ONE_DIM_NONE if od is None else (_lib.LSE_ONE_DIM_LEARNED if isinstance(od, ThreeToOne) else _lib.LSE_ONE_DIM_GRAY)
+        fields = (int(plan["rgb_mapper"] is not None), kinds[type(plan["rgb_mapper"])], kinds[type(plan["ev_mapper"])], one_dim,
+                  plan["deblur_group"], float(cfg.evs_loss_weight))
+        coeff = lambda m: m.pow_coeff if isinstance(m, Powpow) else None
+        return fields, coeff(plan["rgb_mapper"]), coeff(plan["ev_mapper"]), (od.weights if isinstance(od, ThreeToOne) else None)
+
+    def fused_loss_dict(self, raw_outputs: Dict[str, Optional[Dict[str, Tensor]]], batch) -> Dict[str, Tensor]:
+        """Training losses straight from the three bundles' ``exec_get_outputs`` results ({"col_out", "prev_out", "next_out"},
+        each the raw render or None): routing, mappers, deblur mean and both MSEs run in one forward and one backward launch.
+        Same values as ``get_loss_dict`` over ``route_outputs`` (tests/test_gpu_configs.py)."""
+        assert self.training, "the fused epilogue is the training-mode routing"
+        desc = self._epilogue_desc()
+        col, prev, nxt = (raw_outputs.get(k) for k in ("col_out", "prev_out", "next_out"))
+        if desc is None:
+            routed = {k: (self.route_outputs(v, None, ev_out=(k != "col_out")) if v is not None else None)
+                      for k, v in (("col_out", col), ("prev_out", prev), ("next_out", nxt))}
+            return self.get_loss_dict(routed, batch)
+        fields, pow_rgb, pow_evs, w31 = desc
+        rgb_loss, event_loss = ops.loss_epilogue(
+            fields, col["rgb"] if col is not None else None, batch["col_batch"]["image"] if col is not None else None,
+            prev["rgb"] if prev is not None else None, nxt["rgb"] if nxt is not None else None,
+            batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31)
+        losses = {}
+        if col is not None:
+            losses["rgb_loss"] = rgb_loss
+        if prev is not None:
+            losses["event_loss"] = event_loss
+        return losses

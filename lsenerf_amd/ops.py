@@ -640,6 +640,60 @@ def volume_render_depth(t_starts, t_ends, sigmas, rgb, packed_info):
 
 
 # ----------------------------------------------------------------------------------------------------
+# training epilogue: routing + mappers + losses
+# ----------------------------------------------------------------------------------------------------
+class _LossEpilogueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, desc_fields, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31):
+        dev = (col_rgb if col_rgb is not None else prev_rgb).device
+        desc = _lib.EpilogueDesc(*desc_fields)
+        group = desc.deblur_group
+        n_col = col_rgb.shape[0] // group if col_rgb is not None else 0
+        n_ev = prev_rgb.shape[0] if prev_rgb is not None else 0
+        if col_rgb is not None and (col_rgb.shape[0] % group != 0 or col_gt.shape[0] != n_col):
+            raise ValueError(f"colour bundle of {col_rgb.shape[0]} rays does not split into groups of {group} for {col_gt.shape[0]} targets")
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
+                  n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
+                  n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  ctypes.c_void_p(losses.data_ptr()), _stream())
+        ctx.save_for_backward(col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31)
+        ctx.desc_fields, ctx.n_col, ctx.n_ev = desc_fields, n_col, n_ev
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_evs):
+        col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31 = ctx.saved_tensors
+        dev = (col_rgb if col_rgb is not None else prev_rgb).device
+        desc = _lib.EpilogueDesc(*ctx.desc_fields)
+        g_rgb = g_rgb.reshape(1).contiguous().float() if g_rgb is not None else None
+        g_evs = g_evs.reshape(1).contiguous().float() if g_evs is not None else None
+        d_col = torch.empty_like(col_rgb) if col_rgb is not None else None
+        d_prev = torch.empty_like(prev_rgb) if prev_rgb is not None else None
+        d_next = torch.empty_like(next_rgb) if next_rgb is not None else None
+        d_sc = torch.empty(5, dtype=torch.float32, device=dev)
+        _lib.call("lse_loss_epilogue_bwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
+                  ctx.n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
+                  ctx.n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(d_col, "d_col", True),
+                  _f32(d_prev, "d_prev", True), _f32(d_next, "d_next", True), ctypes.c_void_p(d_sc.data_ptr()), _stream())
+        return (None, d_col, None, d_prev, d_next, None,
+                d_sc[0:1].view_as(pow_rgb) if pow_rgb is not None else None,
+                d_sc[1:2].view_as(pow_evs) if pow_evs is not None else None,
+                d_sc[2:5].view_as(w31) if w31 is not None else None)
+
+
+def loss_epilogue(desc_fields: tuple, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb=None, pow_evs=None, w31=None):
+    """Routing + intensity mappers + rgb MSE + log-intensity event MSE in one launch (lse_loss_epilogue_fwd).
+    ``desc_fields`` = (rgb_mapped, rgb_mapper, evs_mapper, ev_one_dim, deblur_group, evs_loss_weight).
+    Returns (rgb_loss, event_loss) as 0-dim tensors."""
+    c = lambda t: _c(t.float()) if t is not None else None
+    return _LossEpilogueFn.apply(tuple(desc_fields), c(col_rgb), c(col_gt), c(prev_rgb), c(next_rgb),
+                                 c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31)
+
+
+# ----------------------------------------------------------------------------------------------------
 # optimiser / occupancy grid
 # ----------------------------------------------------------------------------------------------------
 @torch.no_grad()

@@ -158,3 +158,90 @@ def test_deblur_ray_tiling_and_time_interpolated_poses():
     cams.set_interpolator(spl)
     r = cams.generate_rays(torch.tensor([4]), torch.tensor([[240.0, 320.0]]))
     assert torch.allclose(r.origins[0], torch.from_numpy(c2w[4][:3, 3]), atol=1e-5)
+
+
+def test_se3_exponential_matches_scipy_expm_and_drives_the_optimizer():
+    """mode="SE3" (R:lse_nerf/ns_camera_optimizer.py:276-277): [R | V v] of the twist (v, omega), against scipy's matrix
+    exponential of the 4x4 twist -- also in the small-angle branch -- and through CameraOptimizer."""
+    from scipy.linalg import expm
+    from lsenerf_amd import RayBundle
+    rng = np.random.default_rng(3)
+    tang = rng.normal(size=(40, 6)) * np.array([1, 1, 1, 1.5, 1.5, 1.5])
+    tang[:8, 3:] *= 1e-3                                                     # Taylor branch (|omega| < 1e-2)
+    tang[8, 3:] = 0.0
+    got = cam.exp_map_SE3(torch.tensor(tang, dtype=torch.float64)).numpy()
+    for k in range(40):
+        v, w = tang[k, :3], tang[k, 3:]
+        twist = np.zeros((4, 4))
+        twist[:3, :3] = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        twist[:3, 3] = v
+        assert np.abs(got[k] - expm(twist)[:3, :4]).max() < 1e-9, k
+    got32 = cam.exp_map_SE3(torch.tensor(tang, dtype=torch.float32)).numpy()
+    assert np.abs(got32 - got).max() < 1e-5                                  # the reference's own bar
+    opt = cam.CameraOptimizerConfig(mode="SE3").setup(num_cameras=3, device="cpu")
+    with torch.no_grad():
+        opt.pose_adjustment[2] = torch.tensor([0.3, -0.1, 0.2, 0.0, 0.0, np.pi / 2])
+    o, d = torch.zeros(2, 3), torch.tensor([[1.0, 0, 0], [1.0, 0, 0]])
+    rb = RayBundle(o.clone(), d.clone(), camera_indices=torch.tensor([[0], [2]]))
+    opt.apply_to_raybundle(rb)
+    assert torch.allclose(rb.directions[0], d[0]) and torch.allclose(rb.directions[1], torch.tensor([0.0, 1, 0]), atol=1e-6)
+    twist = np.zeros((4, 4)); twist[0, 1], twist[1, 0] = -np.pi / 2, np.pi / 2; twist[:3, 3] = [0.3, -0.1, 0.2]
+    assert np.abs(rb.origins[1].detach().numpy() - expm(twist)[:3, 3]).max() < 1e-6    # translation couples with rotation
+    rb.origins.sum().backward()
+    assert float(opt.pose_adjustment.grad[2, 3:].abs().sum()) > 0
+
+
+def test_prev_next_optimizer_alternates_and_prefixes():
+    """R:lse_nerf/ns_camera_optimizer.py:368-414."""
+    from lsenerf_amd import RayBundle
+    pn = cam.CameraOptimizerConfig(mode="SO3xR3", optim_type="prevnext").setup(num_cameras=4, device="cpu")
+    assert isinstance(pn, cam.PrevNextCamOptimizer)
+    with torch.no_grad():
+        pn.prev_optim.pose_adjustment[:, 0] = 1.0
+        pn.next_optim.pose_adjustment[:, 1] = 2.0
+    mk = lambda: RayBundle(torch.zeros(3, 3), torch.tensor([[0.0, 0, 1]] * 3), camera_indices=torch.tensor([[0], [1], [3]]))
+    a, b, c = mk(), mk(), mk()
+    pn.apply_to_raybundle(a); pn.apply_to_raybundle(b); pn.apply_to_raybundle(c)
+    assert a.origins[:, 0].tolist() == [1.0] * 3 and a.origins[:, 1].tolist() == [0.0] * 3          # prev
+    assert b.origins[:, 1].tolist() == [2.0] * 3 and b.origins[:, 0].tolist() == [0.0] * 3          # next
+    assert torch.equal(c.origins, a.origins)                                                         # prev again
+    ld, md, pg = {}, {}, {}
+    pn.get_loss_dict(ld); pn.get_metrics_dict(md); pn.get_param_groups(pg)
+    assert set(ld) == {"prev_camera_opt_regularizer", "next_camera_opt_regularizer"}
+    assert set(pg) == {"prev_camera_opt", "next_camera_opt"} and "next_camera_opt_translation" in md
+    with pytest.raises(AssertionError):
+        pn(torch.tensor([0]))
+    delayed = cam.CameraOptimizerConfig(mode="SO3xR3", optim_type="prevnext", scheme="delayed", delay_cnt=3).setup(
+        num_cameras=2, device="cpu")
+    assert len(list(delayed.parameters())) == 2 and not delayed.prev_optim.is_on
+    delayed.update_mode(4)
+    assert delayed.prev_optim.is_on and delayed.next_optim.is_on
+
+
+def test_event_ray_generators():
+    """R:lse_nerf/lse_ray_generator.py:36-100: the same pixels seen from (c, c+1) or from a prev / next camera set."""
+    cams, c2w, ts = _cameras()
+    idx = torch.tensor([[0, 10, 20], [4, 479, 639], [2, 240, 320]])
+    gen = cam.RayGenerator(cams, cam.CameraOptimizerConfig(mode="SO3xR3").setup(num_cameras=len(cams), device="cpu"))
+    rb = gen(idx)
+    want = cams.generate_rays(idx[:, 0], torch.tensor([[10.0, 20.0], [479.0, 639.0], [240.0, 320.0]]))
+    assert torch.allclose(rb.origins, want.origins) and torch.allclose(rb.directions, want.directions, atol=1e-6)
+    prev, nxt = cam.ConsecRayGenerator(cams)(idx)
+    assert torch.allclose(prev.origins, torch.from_numpy(c2w[[0, 4, 2], :3, 3]))
+    assert torch.allclose(nxt.origins, torch.from_numpy(c2w[[1, 5, 3], :3, 3]))
+    assert prev.camera_indices.reshape(-1).tolist() == [0, 4, 2] and nxt.camera_indices.reshape(-1).tolist() == [1, 5, 3]
+    # same pixel, same intrinsics: in camera coordinates the directions coincide
+    R0, R1 = torch.from_numpy(c2w[0][:3, :3]), torch.from_numpy(c2w[1][:3, :3])
+    assert torch.allclose(R0.T @ prev.directions[0], R1.T @ nxt.directions[0], atol=1e-5)
+    c2w_b, _ = gen_data(8, seed=5)
+    cams_b = cam.EdCameras(torch.from_numpy(c2w_b), cams.fx, cams.fy, cams.cx, cams.cy, cams.width, cams.height,
+                           times=torch.from_numpy(ts))
+    p2, n2 = cam.PrevNextRayGenerator(cams, cams_b)(idx)
+    assert torch.allclose(p2.origins, prev.origins) and torch.allclose(n2.origins, torch.from_numpy(c2w_b[[0, 4, 2], :3, 3]))
+    assert n2.camera_indices.reshape(-1).tolist() == [0, 4, 2]
+    # deblur generator = the tiling function behind the nn.Module interface
+    spl = cam.CameraOptimizerConfig(mode="SO3xR3", optim_type="spline", exp_t=0.2).setup(
+        num_cameras=len(cams), device="cpu", cameras=cams, dM=torch.eye(4))
+    cams.set_interpolator(spl)
+    rb4 = cam.DeblurRayGenerator(cams)(idx)
+    assert len(rb4) == 12 and rb4.camera_indices.reshape(-1).tolist() == [0] * 4 + [4] * 4 + [2] * 4
