@@ -69,7 +69,9 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
     #  through the estimator's after_march_hook -- dist.GradPipeline.attach)
     opt.zero_grad()
     out = model.render_packed(rb, ri, ts, te, packed)
-    loss = torch.nn.functional.mse_loss(out["rgb"], target)
+    # routing (training clamp) + rgb MSE in the fused epilogue kernel pair, as the training step does
+    loss = model.fused_loss_dict({"col_out": out, "prev_out": None, "next_out": None},
+                                 {"col_batch": {"image": target}, "evs_batch": None})["rgb_loss"]
     loss.backward()
     if pipeline is not None:
         pipeline.start()
@@ -159,7 +161,8 @@ def context_default_config(device, steps=20, warmup=6):
         opt.zero_grad()
         rb.origins.grad = rb.directions.grad = None
         out = model.exec_get_outputs(rb)
-        torch.nn.functional.mse_loss(out["rgb"], target).backward()
+        model.fused_loss_dict({"col_out": out, "prev_out": None, "next_out": None},
+                              {"col_batch": {"image": target}, "evs_batch": None})["rgb_loss"].backward()
         opt.step()
         step.last = out
 
@@ -205,7 +208,8 @@ def context_m_packed(device, steps=12, warmup=4):
         opt.zero_grad()
         rb.origins.grad = rb.directions.grad = None
         out = model.render_packed(rb, ri, ts, te, packed)
-        torch.nn.functional.mse_loss(out["rgb"], target).backward()
+        model.fused_loss_dict({"col_out": out, "prev_out": None, "next_out": None},
+                              {"col_batch": {"image": target}, "evs_batch": None})["rgb_loss"].backward()
         opt.step()
 
     ms, kern, _ = _timed_steps(step, steps, warmup)

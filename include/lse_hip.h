@@ -64,6 +64,12 @@ typedef struct lse_mlp_desc {
     int32_t n_hidden_layers; /* 1 or 2                                              */
     int32_t out_activation;  /* LSE_ACT_*                                           */
     int32_t in_layout;       /* LSE_IN_*                                            */
+    /* optional first-layer VIEW into params / d_params (all zero = the plain layout above):
+     * W_0[row][c] = params[row * w0_ld + w0_col + c] for c < n_in, the other layers follow at params + width * w0_ld.
+     * w0_mask_col0: input column 0 has no weight (reads 0, gets no gradient).  The head MLP uses (w0_ld 64, w0_col 15,
+     * mask 1): its per-sample input h[N,16] = [density logit | 15 geometry features] meets columns 16..30 of tcnn's
+     * [width x 64] input matrix in place (R:lse_nerf/lse_field.py:254-262, :347-356) -- no per-step split copy. */
+    int32_t w0_ld, w0_col, w0_mask_col0;
 } lse_mlp_desc;
 
 /* ---- misc -------------------------------------------------------------------------------------------- */
@@ -97,6 +103,12 @@ int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, 
 /* nerfacc.pack_info (R:lse_nerf/lsenerf.py:300): packed_info[R,2] = (exclusive cumsum, count); total[1]. */
 int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info, int64_t *total,
                               lse_stream_t stream);
+
+/* Per-ray near / far planes of R:lse_nerf/lse_grid_estimator.py:83-92 in one launch (bit-identical to the torch ops):
+ * near = max(near_plane, t_min[r]) (+ jitter[r] * step_size when jitter is given: stratified sampling),
+ * far = min(far_plane, t_max[r]).  t_min / t_max / jitter are nullable. */
+int lse_ray_planes(float near_plane, float far_plane, const float *t_min, const float *t_max, const float *jitter,
+                   float step_size, int32_t n_rays, float *near_planes, float *far_planes, lse_stream_t stream);
 
 /* nerfacc.render_visibility_from_density (R:lse_nerf/lse_grid_estimator.py:120-127): mask[N] uint8 and the
  * per-ray surviving counts new_cnts[R]. */
@@ -209,6 +221,18 @@ int lse_ray_features_bwd(const float *rays_d, const float *d_feat, const int32_t
                          int32_t emb_dim, int32_t n_emb_rows, float *d_rays_d, float *d_emb_table, lse_stream_t stream);
 /* small dense helpers on per-ray matrices: y[R,M] = x[R,K] W[M,K]^T ; dx[R,K] = dy[R,M] W[M,K] ;
  * dW[M,K] += dy^T x. */
+/* The same features AND the per-ray share of the head's first layer in one launch:
+ *   feat[R, in_pad] = [SH16 | 0 x 15 | emb (emb_dim) | ones padding],  in_pad = roundup(31 + emb_dim, 16)  (tcnn's layout)
+ *   row_bias[R, width] = feat * W_in^T with W_in[width][w_ld] the head's tcnn input matrix in place.
+ * Backward: d_feat[R, in_pad] = d_row_bias * W_in (workspace, overwritten), d_rays_d[R,3] (nullable) through the SH
+ * Jacobian, d_emb_table[n_emb_rows, emb_dim] (nullable, accumulate).  The weight gradient d W_in += d_row_bias^T feat is
+ * lse_gemm_tn_acc(d_row_bias, width, feat, in_pad, ..., dw_ld = w_ld) straight into the parameter gradient. */
+int lse_ray_bias_fwd(const float *rays_d, const float *emb_table, const int32_t *emb_idx, int32_t n_rays,
+                     int32_t emb_dim, const float *w_in, int32_t w_ld, int32_t width, float *feat, float *row_bias,
+                     lse_stream_t stream);
+int lse_ray_bias_bwd(const float *rays_d, const int32_t *emb_idx, int32_t n_rays, int32_t emb_dim, int32_t n_emb_rows,
+                     const float *w_in, int32_t w_ld, int32_t width, const float *d_row_bias, float *d_feat,
+                     float *d_rays_d, float *d_emb_table, lse_stream_t stream);
 int lse_linear_fwd(const float *w, const float *x, int32_t rows, int32_t m, int32_t k, float *y, lse_stream_t stream);
 int lse_linear_bwd_input(const float *w, const float *dy, int32_t rows, int32_t m, int32_t k, float *dx,
                          lse_stream_t stream);

@@ -40,7 +40,7 @@ LSE_ONE_DIM_NONE, LSE_ONE_DIM_LEARNED, LSE_ONE_DIM_GRAY = 0, 1, 2
 
 class MlpDesc(Structure):
     _fields_ = [("n_in", c_int32), ("width", c_int32), ("n_hidden_layers", c_int32), ("out_activation", c_int32),
-                ("in_layout", c_int32)]
+                ("in_layout", c_int32), ("w0_ld", c_int32), ("w0_col", c_int32), ("w0_mask_col0", c_int32)]
 
 
 P = c_void_p
@@ -52,6 +52,7 @@ SIGNATURES = {
     "lse_traverse_grids_slots": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I64, P, P, P, P, P],
     "lse_compact_ray_slots": [P, P, I64, P, I32, P, P, P, P],
     "lse_pack_info_from_counts": [P, I32, P, P, P],
+    "lse_ray_planes": [F32, F32, P, P, P, F32, I32, P, P, P],
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
     "lse_visibility_mask_alpha": [P, P, I32, F32, F32, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
@@ -70,6 +71,8 @@ SIGNATURES = {
     "lse_segment_sum_rows": [P, I32, P, I32, P, P],
     "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],
     "lse_ray_features_bwd": [P, P, P, I32, I32, I32, P, P, P],
+    "lse_ray_bias_fwd": [P, P, P, I32, I32, P, I32, I32, P, P, P],
+    "lse_ray_bias_bwd": [P, P, I32, I32, I32, P, I32, I32, P, P, P, P, P],
     "lse_linear_fwd": [P, P, I32, I32, I32, P, P],
     "lse_linear_bwd_input": [P, P, I32, I32, I32, P, P],
     "lse_gemm_tn_acc": [P, I32, P, I32, I32, I64, P, I32, P],

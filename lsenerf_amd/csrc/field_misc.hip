@@ -171,6 +171,31 @@ __device__ __forceinline__ void sh4(float x, float y, float z, float *o)
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// gradient of sum_k g[k] * sh4(x, y, z)[k] w.r.t. (x, y, z)
+__device__ __forceinline__ void sh4_grad(float x, float y, float z, const float *g, float &gx, float &gy, float &gz)
+{
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        const float c1 = 0.48860251190291987f, c4 = 1.0925484305920792f, c6 = 0.94617469575755997f,
+                    c8 = 0.54627421529603959f, c9 = 0.59004358992664352f, c10 = 2.8906114426405538f,
+                    c11 = 0.45704579946446572f, c12 = 0.3731763325901154f, c14 = 1.4453057213202769f;
+    gx = 0.f; gy = 0.f; gz = 0.f;
+        gy += g[1] * -c1;
+        gz += g[2] * c1;
+        gx += g[3] * -c1;
+        gx += g[4] * c4 * y;            gy += g[4] * c4 * x;
+        gy += g[5] * -c4 * z;           gz += g[5] * -c4 * y;
+        gz += g[6] * 2.f * c6 * z;
+        gx += g[7] * -c4 * z;           gz += g[7] * -c4 * x;
+        gx += g[8] * 2.f * c8 * x;      gy += g[8] * -2.f * c8 * y;
+        gx += g[9] * c9 * y * -6.f * x; gy += g[9] * c9 * (-3.f * x2 + 3.f * y2);
+        gx += g[10] * c10 * y * z;      gy += g[10] * c10 * x * z;     gz += g[10] * c10 * x * y;
+        gy += g[11] * c11 * (1.f - 5.f * z2);                          gz += g[11] * c11 * y * -10.f * z;
+        gz += g[12] * c12 * (15.f * z2 - 3.f);
+        gx += g[13] * c11 * (1.f - 5.f * z2);                          gz += g[13] * c11 * x * -10.f * z;
+        gx += g[14] * c14 * z * 2.f * x; gy += g[14] * c14 * z * -2.f * y; gz += g[14] * c14 * (x2 - y2);
+        gx += g[15] * c9 * (-3.f * x2 + 3.f * y2);                     gy += g[15] * c9 * x * 6.f * y;
+}
+
 __global__ __launch_bounds__(256) void ray_features_fwd_kernel(const float *__restrict__ dirs,
                                                                const float *__restrict__ emb,
                                                                const int32_t *__restrict__ eidx, int n_rays, int emb_dim,
@@ -207,26 +232,8 @@ __global__ __launch_bounds__(256) void ray_features_bwd_kernel(const float *__re
         const float x = ((dirs[r * 3 + 0] + 1.f) / 2.f) * 2.f - 1.f;
         const float y = ((dirs[r * 3 + 1] + 1.f) / 2.f) * 2.f - 1.f;
         const float z = ((dirs[r * 3 + 2] + 1.f) / 2.f) * 2.f - 1.f;
-        const float x2 = x * x, y2 = y * y, z2 = z * z;
-        const float c1 = 0.48860251190291987f, c4 = 1.0925484305920792f, c6 = 0.94617469575755997f,
-                    c8 = 0.54627421529603959f, c9 = 0.59004358992664352f, c10 = 2.8906114426405538f,
-                    c11 = 0.45704579946446572f, c12 = 0.3731763325901154f, c14 = 1.4453057213202769f;
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        gy += g[1] * -c1;
-        gz += g[2] * c1;
-        gx += g[3] * -c1;
-        gx += g[4] * c4 * y;            gy += g[4] * c4 * x;
-        gy += g[5] * -c4 * z;           gz += g[5] * -c4 * y;
-        gz += g[6] * 2.f * c6 * z;
-        gx += g[7] * -c4 * z;           gz += g[7] * -c4 * x;
-        gx += g[8] * 2.f * c8 * x;      gy += g[8] * -2.f * c8 * y;
-        gx += g[9] * c9 * y * -6.f * x; gy += g[9] * c9 * (-3.f * x2 + 3.f * y2);
-        gx += g[10] * c10 * y * z;      gy += g[10] * c10 * x * z;     gz += g[10] * c10 * x * y;
-        gy += g[11] * c11 * (1.f - 5.f * z2);                          gz += g[11] * c11 * y * -10.f * z;
-        gz += g[12] * c12 * (15.f * z2 - 3.f);
-        gx += g[13] * c11 * (1.f - 5.f * z2);                          gz += g[13] * c11 * x * -10.f * z;
-        gx += g[14] * c14 * z * 2.f * x; gy += g[14] * c14 * z * -2.f * y; gz += g[14] * c14 * (x2 - y2);
-        gx += g[15] * c9 * (-3.f * x2 + 3.f * y2);                     gy += g[15] * c9 * x * 6.f * y;
+        float gx, gy, gz;
+        sh4_grad(x, y, z, g, gx, gy, gz);
         // d v / d dir = (1/2)*2 = 1
         d_dirs[r * 3 + 0] = gx; d_dirs[r * 3 + 1] = gy; d_dirs[r * 3 + 2] = gz;
     }
@@ -236,7 +243,8 @@ __global__ __launch_bounds__(256) void ray_features_bwd_kernel(const float *__re
 // handful of rows, so atomics would pile onto a few addresses (14x slower per MI355X_MICROARCH.md "contention");
 // instead one workgroup per embedding row scans the ray list (R is a few thousand) and reduces in LDS.
 __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__ dfeat, const int32_t *__restrict__ eidx,
-                                                       int n_rays, int emb_dim, float *__restrict__ d_emb)
+                                                       int n_rays, int emb_dim, float *__restrict__ d_emb,
+                                                       int feat_ld = 64)
 {
     // thread (part, col): 8 ray-partitions x 32 columns; the ray-id test is wave-uniform per iteration (all 32 column
     // lanes of a partition look at the same ray), partial sums stay in a register, one LDS pass combines the partitions.
@@ -251,14 +259,14 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__
     for (; r + 4 <= r1; r += 4) {   // 4 independent id loads in flight
         const int i0 = eidx[r], i1 = eidx[r + 1], i2 = eidx[r + 2], i3 = eidx[r + 3];
         if (col < emb_dim) {
-            if (i0 == e) acc += dfeat[(int64_t)r * 64 + 31 + col];
-            if (i1 == e) acc += dfeat[(int64_t)(r + 1) * 64 + 31 + col];
-            if (i2 == e) acc += dfeat[(int64_t)(r + 2) * 64 + 31 + col];
-            if (i3 == e) acc += dfeat[(int64_t)(r + 3) * 64 + 31 + col];
+            if (i0 == e) acc += dfeat[(int64_t)r * feat_ld + 31 + col];
+            if (i1 == e) acc += dfeat[(int64_t)(r + 1) * feat_ld + 31 + col];
+            if (i2 == e) acc += dfeat[(int64_t)(r + 2) * feat_ld + 31 + col];
+            if (i3 == e) acc += dfeat[(int64_t)(r + 3) * feat_ld + 31 + col];
         }
     }
     for (; r < r1; ++r)
-        if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * 64 + 31 + col];
+        if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * feat_ld + 31 + col];
     red[part][col] = acc;
     __syncthreads();
     if (part == 0 && col < emb_dim) {
@@ -266,6 +274,93 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__
 #pragma unroll
         for (int p = 0; p < 8; ++p) s += red[p][col];
         atomicAdd(&d_emb[(int64_t)e * emb_dim + col], s);
+    }
+}
+
+// ---- per-ray part of the head's first layer, fused ------------------------------------------------------------------
+// tcnn feeds the head [SH16 | geo15 | emb | ones-padding] (R:lse_nerf/lse_field.py:347-356; padded to a multiple of 16 with
+// ones).  Everything but the 15 geometry features depends only on the RAY, so it enters layer 0 as a per-ray bias
+//     row_bias[r][o] = sum_c feat[r][c] * W_in[o][c],   feat[r] = [SH16(dir_r) | 0 x 15 | emb[idx_r] | 1 ...]  (in_pad wide)
+// computed here in one launch (feature construction + the [R x in_pad] x [in_pad x W] product); feat is kept for the backward.
+constexpr int kRbRays = 16;     // rays per workgroup
+
+__device__ __forceinline__ void ray_feat(const float *dirs, const float *emb, const int32_t *eidx, int r, int emb_dim,
+                                         int in_dim, int in_pad, float *f /* [in_pad], LDS or registers */)
+{
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = ((dirs[r * 3 + k] + 1.f) / 2.f) * 2.f - 1.f;   // shift_directions_for_tcnn, tcnn's 2x-1
+    float sh[16];
+    sh4(v[0], v[1], v[2], sh);
+    for (int k = 0; k < 16; ++k) f[k] = sh[k];
+    for (int k = 16; k < 31; ++k) f[k] = 0.f;
+    const int64_t e = (emb && eidx) ? eidx[r] : 0;
+    for (int k = 0; k < emb_dim; ++k) f[31 + k] = emb ? emb[e * emb_dim + k] : 0.f;
+    for (int k = in_dim; k < in_pad; ++k) f[k] = 1.f;                               // tcnn pads network inputs with ones
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(256) void ray_bias_fwd_kernel(const float *__restrict__ dirs, const float *__restrict__ emb,
+                                                           const int32_t *__restrict__ eidx, int n_rays, int emb_dim,
+                                                           int in_pad, const float *__restrict__ W /* [WIDTH][w_ld] */,
+                                                           int w_ld, float *__restrict__ feat, float *__restrict__ row_bias)
+{
+    __shared__ float s_f[kRbRays][65];
+    __shared__ float s_w[WIDTH][65];
+    const int in_dim = 31 + emb_dim;
+    const int r0 = blockIdx.x * kRbRays;
+    for (int e = threadIdx.x; e < WIDTH * in_pad; e += 256) s_w[e / in_pad][e % in_pad] = W[(e / in_pad) * w_ld + e % in_pad];
+    if (threadIdx.x < kRbRays && r0 + (int)threadIdx.x < n_rays)
+        ray_feat(dirs, emb, eidx, r0 + threadIdx.x, emb_dim, in_dim, in_pad, s_f[threadIdx.x]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < kRbRays * in_pad; e += 256) {
+        const int rr = e / in_pad, c = e % in_pad;
+        if (r0 + rr < n_rays) feat[(int64_t)(r0 + rr) * in_pad + c] = s_f[rr][c];
+    }
+    for (int e = threadIdx.x; e < kRbRays * WIDTH; e += 256) {
+        const int rr = e / WIDTH, o = e % WIDTH;
+        if (r0 + rr >= n_rays) continue;
+        float acc = 0.f;
+        for (int c = 0; c < in_pad; ++c) acc = fmaf(s_f[rr][c], s_w[o][c], acc);
+        row_bias[(int64_t)(r0 + rr) * WIDTH + o] = acc;
+    }
+}
+
+// d_feat = d_row_bias * W_in  ->  d(directions) through the SH Jacobian, and the embedding slice [R, 32] for emb_grad_kernel
+template <int WIDTH>
+__global__ __launch_bounds__(256) void ray_bias_bwd_kernel(const float *__restrict__ dirs, const float *__restrict__ d_rb,
+                                                           int n_rays, int emb_dim, int in_pad,
+                                                           const float *__restrict__ W, int w_ld,
+                                                           float *__restrict__ d_feat /* [R][in_pad] */,
+                                                           float *__restrict__ d_dirs /* nullable */)
+{
+    __shared__ float s_g[kRbRays][WIDTH + 1];
+    __shared__ float s_w[WIDTH][65];
+    __shared__ float s_df[kRbRays][65];
+    const int r0 = blockIdx.x * kRbRays;
+    for (int e = threadIdx.x; e < WIDTH * in_pad; e += 256) s_w[e / in_pad][e % in_pad] = W[(e / in_pad) * w_ld + e % in_pad];
+    for (int e = threadIdx.x; e < kRbRays * WIDTH; e += 256) {
+        const int rr = e / WIDTH, o = e % WIDTH;
+        s_g[rr][o] = (r0 + rr < n_rays) ? d_rb[(int64_t)(r0 + rr) * WIDTH + o] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kRbRays * in_pad; e += 256) {
+        const int rr = e / in_pad, c = e % in_pad;
+        float acc = 0.f;
+        for (int o = 0; o < WIDTH; ++o) acc = fmaf(s_g[rr][o], s_w[o][c], acc);
+        s_df[rr][c] = acc;
+        if (r0 + rr < n_rays) d_feat[(int64_t)(r0 + rr) * in_pad + c] = acc;
+    }
+    __syncthreads();
+    if (d_dirs && threadIdx.x < kRbRays && r0 + (int)threadIdx.x < n_rays) {
+        const int r = r0 + threadIdx.x;
+        const float *g = s_df[threadIdx.x];
+        const float x = ((dirs[r * 3 + 0] + 1.f) / 2.f) * 2.f - 1.f;
+        const float y = ((dirs[r * 3 + 1] + 1.f) / 2.f) * 2.f - 1.f;
+        const float z = ((dirs[r * 3 + 2] + 1.f) / 2.f) * 2.f - 1.f;
+        float gx, gy, gz;
+        sh4_grad(x, y, z, g, gx, gy, gz);
+        d_dirs[r * 3 + 0] = gx; d_dirs[r * 3 + 1] = gy; d_dirs[r * 3 + 2] = gz;
     }
 }
 
@@ -368,4 +463,52 @@ extern "C" int lse_ray_features_bwd(const float *rays_d, const float *d_feat, co
         hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows, 8), dim3(256), 0, lse::as_stream(stream), d_feat, emb_idx, n_rays,
                            emb_dim, d_emb_table);
     return lse::check_launch("lse_ray_features_bwd");
+}
+
+extern "C" int lse_ray_bias_fwd(const float *rays_d, const float *emb_table, const int32_t *emb_idx, int32_t n_rays,
+                                int32_t emb_dim, const float *w_in, int32_t w_ld, int32_t width, float *feat,
+                                float *row_bias, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_ray_bias_fwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(rays_d && w_in && feat && row_bias, "lse_ray_bias_fwd: null pointer");
+    LSE_REQUIRE(emb_dim == 0 || emb_dim == 32, "lse_ray_bias_fwd: emb_dim must be 0 or 32 (got %d)", emb_dim);
+    LSE_REQUIRE(width == 32 || width == 64, "lse_ray_bias_fwd: width %d not in {32,64}", width);
+    const int in_pad = (31 + emb_dim + 15) / 16 * 16;
+    LSE_REQUIRE(w_ld >= in_pad, "lse_ray_bias_fwd: w_ld %d < padded input width %d", w_ld, in_pad);
+    const dim3 grid((n_rays + kRbRays - 1) / kRbRays);
+    if (width == 64)
+        hipLaunchKernelGGL((ray_bias_fwd_kernel<64>), grid, dim3(256), 0, lse::as_stream(stream), rays_d, emb_table, emb_idx,
+                           n_rays, emb_dim, in_pad, w_in, w_ld, feat, row_bias);
+    else
+        hipLaunchKernelGGL((ray_bias_fwd_kernel<32>), grid, dim3(256), 0, lse::as_stream(stream), rays_d, emb_table, emb_idx,
+                           n_rays, emb_dim, in_pad, w_in, w_ld, feat, row_bias);
+    return lse::check_launch("lse_ray_bias_fwd");
+}
+
+extern "C" int lse_ray_bias_bwd(const float *rays_d, const int32_t *emb_idx, int32_t n_rays, int32_t emb_dim,
+                                int32_t n_emb_rows, const float *w_in, int32_t w_ld, int32_t width,
+                                const float *d_row_bias, float *d_feat, float *d_rays_d, float *d_emb_table,
+                                lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_ray_bias_bwd: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(rays_d && w_in && d_row_bias && d_feat, "lse_ray_bias_bwd: null pointer");
+    LSE_REQUIRE(emb_dim == 0 || emb_dim == 32, "lse_ray_bias_bwd: emb_dim must be 0 or 32 (got %d)", emb_dim);
+    LSE_REQUIRE(width == 32 || width == 64, "lse_ray_bias_bwd: width %d not in {32,64}", width);
+    LSE_REQUIRE(!d_emb_table || (n_emb_rows > 0 && emb_idx), "lse_ray_bias_bwd: d_emb_table needs n_emb_rows and emb_idx");
+    const int in_pad = (31 + emb_dim + 15) / 16 * 16;
+    LSE_REQUIRE(w_ld >= in_pad, "lse_ray_bias_bwd: w_ld %d < padded input width %d", w_ld, in_pad);
+    hipStream_t st = lse::as_stream(stream);
+    const dim3 grid((n_rays + kRbRays - 1) / kRbRays);
+    if (width == 64)
+        hipLaunchKernelGGL((ray_bias_bwd_kernel<64>), grid, dim3(256), 0, st, rays_d, d_row_bias, n_rays, emb_dim, in_pad, w_in,
+                           w_ld, d_feat, d_rays_d);
+    else
+        hipLaunchKernelGGL((ray_bias_bwd_kernel<32>), grid, dim3(256), 0, st, rays_d, d_row_bias, n_rays, emb_dim, in_pad, w_in,
+                           w_ld, d_feat, d_rays_d);
+    if (d_emb_table && emb_dim > 0)
+        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows, 8), dim3(256), 0, st, d_feat, emb_idx, n_rays, emb_dim,
+                           d_emb_table, in_pad);
+    return lse::check_launch("lse_ray_bias_bwd");
 }

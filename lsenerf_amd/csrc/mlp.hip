@@ -59,6 +59,12 @@ struct MlpArgs {
     int out_cols;                // 16 (padded row) or 4 (compact: only outputs 0..3 are stored / have gradients)
     int act_tiled;               // saved-activation layout: 0 = row-major [N][W], 1 = tile-major (see act_offset)
     int64_t act_layer_stride;    // floats between the activation arrays of consecutive hidden layers
+    // first-layer view into `params` (and `d_params`): W0[row][c] = params[row * w0_ld + w0_col + c], c < n_in; the remaining
+    // layers start at params + rest_off.  w0_mask0: input column 0 carries no weight (reads as 0, receives no gradient).
+    // Lets the head consume the density logit + 15 geometry features h[N,16] against columns 15..30 of tcnn's [W x 64]
+    // input matrix in place -- no split / concatenated copy of the parameters per step.
+    int w0_ld, w0_col, w0_mask0;
+    int64_t rest_off;
 };
 
 // CT = column tiles (of 16 samples) per wave iteration, NW = waves per workgroup (template parameters below).
@@ -85,12 +91,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
     extern __shared__ float lds[];
     float *img0 = lds, *imgH = lds + IMG0 * 64, *imgO = imgH + IMGH * 64;
 
-    const float *W0 = a.params;
-    const float *W1 = W0 + WIDTH * KIN;
+    const float *W0 = a.params + a.w0_col;
+    const float *W1 = a.params + a.rest_off;
     const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
     for (int e = threadIdx.x; e < IMG0 * 64; e += 64 * NW) {
         const int img = e >> 6, ln = e & 63, rb = img / KS0, ks = img % KS0, i = ln & 15, q = ln >> 4;
-        img0[e] = W0[(16 * rb + i) * KIN + kidx_in<INL>(ks, q)];
+        const int c = kidx_in<INL>(ks, q);
+        img0[e] = (a.w0_mask0 && c == 0) ? 0.f : W0[(16 * rb + i) * a.w0_ld + c];
     }
     if (NHL == 2)
         for (int e = threadIdx.x; e < IMGH * 64; e += 64 * NW) {
@@ -357,13 +364,14 @@ __device__ __forceinline__ void wgrad_from_mem(f32x4 (&acc)[MB][(K + 15) / 16], 
 
 // flush persistent accumulator tiles: D row = 4q + r -> m, col = j -> k
 template <int MB, int KB>
-__device__ __forceinline__ void flush_wgrad(float *dw, int ld, int k_real, const f32x4 (&acc)[MB][KB], int j, int q)
+__device__ __forceinline__ void flush_wgrad(float *dw, int ld, int k_real, const f32x4 (&acc)[MB][KB], int j, int q,
+                                            bool skip_col0 = false)
 {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-            if (16 * kb + j < k_real) {
+            if (16 * kb + j < k_real && !(skip_col0 && 16 * kb + j == 0)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(&dw[(16 * mb + 4 * q + r) * ld + 16 * kb + j], acc[mb][kb][r]);
             }
@@ -406,13 +414,13 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
     constexpr int RB0 = (KIN + 15) / 16;
     constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
-    constexpr int NP0 = WIDTH * KIN, NP1 = (NHL - 1) * WIDTH * WIDTH;
+    constexpr int NP1 = (NHL - 1) * WIDTH * WIDTH;
     extern __shared__ float lds[];
     float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
     float *tr_all = imgI + IMGI * 64;                       // NW waves x kTrWave (WGRAD only)
 
-    const float *W0 = a.params;
-    const float *W1 = W0 + WIDTH * KIN;
+    const float *W0 = a.params + a.w0_col;
+    const float *W1 = a.params + a.rest_off;
     const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
     // dH_last^T = Wo^T (WIDTH x 16) * dOut^T : A[i][k] = Wo[k = 4q+ks][16rb+i]
     for (int e = threadIdx.x; e < IMGO * 64; e += 64 * NW) {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
         for (int e = threadIdx.x; e < IMGI * 64; e += 64 * NW) {
             const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
             const int col = 16 * rb + i;
-            imgI[e] = col < KIN ? W0[kidx_blk(ks, q) * KIN + col] : 0.f;
+            imgI[e] = (col < KIN && !(a.w0_mask0 && col == 0)) ? W0[kidx_blk(ks, q) * a.w0_ld + col] : 0.f;
         }
     __syncthreads();
 
@@ -645,9 +653,9 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
         }
     }
     if (WGRAD) {
-        flush_wgrad<HB, KB0>(a.d_params, KIN, KIN, acc0, j, q);
-        if constexpr (NHL == 2) flush_wgrad<HB, HB>(a.d_params + NP0, WIDTH, WIDTH, acc1, j, q);
-        flush_wgrad<1, HB>(a.d_params + NP0 + NP1, WIDTH, WIDTH, accO, j, q);
+        flush_wgrad<HB, KB0>(a.d_params + a.w0_col, a.w0_ld, KIN, acc0, j, q, a.w0_mask0 != 0);
+        if constexpr (NHL == 2) flush_wgrad<HB, HB>(a.d_params + a.rest_off, WIDTH, WIDTH, acc1, j, q);
+        flush_wgrad<1, HB>(a.d_params + a.rest_off + NP1, WIDTH, WIDTH, accO, j, q);
     }
 }
 
@@ -777,7 +785,18 @@ int check_desc(const lse_mlp_desc *d, const char *who)
     LSE_REQUIRE(d->in_layout == LSE_IN_LEVELMAJOR || d->n_in >= 16, "%s: row-major input needs n_in >= 16", who);
     LSE_REQUIRE(d->out_activation == LSE_ACT_NONE || d->out_activation == LSE_ACT_SIGMOID, "%s: bad out_activation",
                 who);
+    LSE_REQUIRE(d->w0_ld == 0 || d->w0_ld >= d->w0_col + d->n_in, "%s: first-layer view [%d, %d) exceeds its leading dimension %d",
+                who, d->w0_col, d->w0_col + d->n_in, d->w0_ld);
+    LSE_REQUIRE(d->w0_col >= 0 && (d->w0_ld != 0 || d->w0_col == 0), "%s: w0_col needs w0_ld", who);
     return LSE_OK;
+}
+
+void fill_view(MlpArgs &a, const lse_mlp_desc *d)
+{
+    a.w0_ld = d->w0_ld ? d->w0_ld : d->n_in;
+    a.w0_col = d->w0_col;
+    a.w0_mask0 = d->w0_mask_col0;
+    a.rest_off = (int64_t)d->width * a.w0_ld;
 }
 
 template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
@@ -926,6 +945,7 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     a.selector = selector; a.density_scale = density_scale;
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
+    fill_view(a, desc);
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_fwd, desc, a, st);
 }
@@ -955,6 +975,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
     a.row_bias_idx = row_bias_idx; a.d_row_bias = d_row_bias;
+    fill_view(a, desc);
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);
 }
@@ -976,6 +997,8 @@ extern "C" int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const fl
     LSE_REQUIRE(n >= 0, "lse_mlp_wgrad: n < 0");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(in && act && d_act && d_out_pre && d_params, "lse_mlp_wgrad: null pointer");
+    LSE_REQUIRE((desc->w0_ld == 0 || desc->w0_ld == desc->n_in) && !desc->w0_mask_col0,
+                "lse_mlp_wgrad: first-layer views are only supported by the fused lse_mlp_bwd");
     hipStream_t st = lse::as_stream(stream);
     const int W = desc->width, K0 = desc->n_in, NHL = desc->n_hidden_layers;
     float *dW0 = d_params, *dW1 = dW0 + W * K0, *dWo = dW1 + (NHL - 1) * W * W;

@@ -390,6 +390,26 @@ __global__ __launch_bounds__(256) void compact_slots_kernel(const float *__restr
     }
 }
 
+// near / far planes per ray exactly as R:lse_nerf/lse_grid_estimator.py:83-92 forms them with torch ops:
+//   near = max(near_plane, t_min[r]);  far = min(far_plane, t_max[r]);  stratified: near += u[r] * step
+// (f32 multiply, then f32 add -- this file is built with -ffp-contract=off, so the two roundings match torch's two kernels).
+__global__ void ray_planes_kernel(float near_plane, float far_plane, const float *__restrict__ t_min,
+                                  const float *__restrict__ t_max, const float *__restrict__ jitter, float step, int n_rays,
+                                  float *__restrict__ near_out, float *__restrict__ far_out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float nr = near_plane, fr = far_plane;
+    if (t_min) nr = fmaxf(nr, t_min[r]);
+    if (t_max) fr = fminf(fr, t_max[r]);
+    if (jitter) {
+        const float j = jitter[r] * step;
+        nr = nr + j;
+    }
+    near_out[r] = nr;
+    far_out[r] = fr;
+}
+
 static int vec_march_enabled()
 {
     return (int)lse::option("traverse_vec");
@@ -472,4 +492,16 @@ extern "C" int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_ra
     hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(1024), 0, lse::as_stream(stream), chunk_cnts, n_rays, packed_info,
                        total);
     return lse::check_launch("lse_pack_info_from_counts");
+}
+
+extern "C" int lse_ray_planes(float near_plane, float far_plane, const float *t_min, const float *t_max,
+                              const float *jitter, float step_size, int32_t n_rays, float *near_planes,
+                              float *far_planes, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_ray_planes: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(near_planes && far_planes, "lse_ray_planes: null pointer");
+    hipLaunchKernelGGL(ray_planes_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, lse::as_stream(stream), near_plane,
+                       far_plane, t_min, t_max, jitter, step_size, n_rays, near_planes, far_planes);
+    return lse::check_launch("lse_ray_planes");
 }

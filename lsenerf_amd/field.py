@@ -329,33 +329,27 @@ class LSEField(nn.Module):
             h, sigma = ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg, density=dens)
         return sigma, h, sel
 
-    def _head_params_split(self):
-        """Split the tcnn head matrix W_in[width, 64|32] into the per-ray part (SH | emb | ones column) and the
-        per-sample part (geo columns, fed from the base output h[N,16] whose column 0 is the density logit)."""
-        head = self.mlp_head
-        W = head.layer_width
-        w_in = head.first_layer()                       # [W, in_pad]
-        zeros1 = torch.zeros(W, 1, device=w_in.device, dtype=w_in.dtype)
-        w_geo16 = torch.cat([zeros1, w_in[:, 16:16 + self.geo_feat_dim]], dim=1)      # [W,16]
-        if self.appearance_embedding_dim > 0:
-            w_ray = w_in                                                               # [W,64], geo slots meet zeros
-        else:
-            w_ray = torch.cat([w_in[:, :31], torch.zeros(W, 32, device=w_in.device, dtype=w_in.dtype),
-                               w_in[:, 31:32]], dim=1)
-        kernel_params = torch.cat([w_geo16.reshape(-1), head.rest()])
-        return w_ray, kernel_params
-
     def rgb_packed(self, h: Tensor, rays_d: Tensor, emb_idx: Optional[Tensor], ray_idx: Optional[Tensor],
                    packed_info: Optional[Tensor], emb_table: Optional[Tensor]) -> Tensor:
         """Fast path of get_outputs: h[N,16] from ``density_packed``; per-ray directions/embedding ids.
-        Returns the compact head output [N,4] (columns 0..2 = RGB)."""
+        Returns the compact head output [N,4] (columns 0..2 = RGB).
+
+        tcnn's head input is [SH16 | geo15 | emb | ones-pad] against W_in[width, in_pad].  The SH / embedding / padding
+        columns depend only on the ray: ``ops.ray_bias`` turns them into a per-ray layer-0 bias in one launch.  The 15
+        geometry columns are per sample: the fused MLP reads h[N,16] (column 0 = density logit) against columns 15..30 of
+        W_in IN PLACE (first-layer view: leading dimension in_pad, column offset 15, column 0 masked) -- the parameter
+        vector is never split or copied, and both kernels accumulate their weight gradients straight into its .grad."""
+        head = self.mlp_head
         n = h.shape[0]
-        feat = ops.ray_features(rays_d, emb_table, emb_idx)                 # [R,64]
-        w_ray, kernel_params = self._head_params_split()
-        row_bias = ops.linear(feat, w_ray)                                   # [R,W]
-        meta = ops.MlpMeta(16, self.mlp_head.layer_width, self.mlp_head.n_hidden_layers, self.mlp_head.out_act,
-                           _lib.LSE_IN_ROWMAJOR)
-        return ops.fused_mlp(kernel_params, h, meta, n, row_bias, ray_idx, packed_info, out_cols=4)
+        emb_dim = 0 if emb_table is None else emb_table.shape[1]
+        if emb_dim != self.appearance_embedding_dim:        # eval mode "zero": the embedding columns meet zeros
+            emb_table = torch.zeros((1, self.appearance_embedding_dim), dtype=h.dtype, device=h.device) \
+                if self.appearance_embedding_dim > 0 else None
+            emb_idx = torch.zeros(rays_d.shape[0], dtype=torch.int32, device=h.device) if emb_table is not None else None
+        row_bias = ops.ray_bias(rays_d, emb_table, emb_idx, head.params, head.layer_width)        # [R, W]
+        meta = ops.MlpMeta(16, head.layer_width, head.n_hidden_layers, head.out_act, _lib.LSE_IN_ROWMAJOR,
+                           w0_ld=head.in_pad, w0_col=15, w0_mask_col0=1)
+        return ops.fused_mlp(head.params, h, meta, n, row_bias, ray_idx, packed_info, out_cols=4)
 
     def _train_emb_table(self):
         if self.embedding_appearance is None:

@@ -78,18 +78,16 @@ class LSEOccGridEstimator(nn.Module):
                  cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False):
         """Sampling with spatial skipping (not differentiable).  Returns (ray_indices, t_starts, t_ends); with
         ``return_packed`` also ``packed_info`` and ray_indices stays int32."""
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
-        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
-        if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
-        if t_max is not None:
-            far_planes = torch.clamp(far_planes, max=t_max)
+        # near / far planes clamped by t_min / t_max, stratified start offset u * step (one launch, bit-identical to the
+        # reference's full_like / clamp / rand_like-multiply-add sequence)
+        u = None
         if stratified:
-            u = jitter if jitter is not None else torch.rand_like(near_planes)
-            near_planes = near_planes + u * render_step_size
+            u = jitter if jitter is not None else torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device)
+        near_planes, far_planes = ops.ray_planes(rays_o.shape[0], rays_o.device, near_plane, far_plane, t_min, t_max, u,
+                                                 render_step_size)
         ray_indices, t_starts, t_ends, packed_info = ops.traverse_grids(
-            rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes.contiguous(),
-            far_planes.contiguous(), render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane))
+            rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
+            render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane))
 
         if self.after_march_hook is not None:   # e.g. finish the previous step's all-reduce + Adam (dist.GradPipeline)
             self.after_march_hook()

@@ -105,13 +105,17 @@ class MlpMeta:
     n_hidden_layers: int
     out_activation: int = _lib.LSE_ACT_NONE
     in_layout: int = _lib.LSE_IN_ROWMAJOR
+    w0_ld: int = 0            # first-layer view into params (include/lse_hip.h: lse_mlp_desc); 0 = plain layout
+    w0_col: int = 0
+    w0_mask_col0: int = 0
 
     @property
     def n_params(self):
-        return self.width * self.n_in + (self.n_hidden_layers - 1) * self.width * self.width + 16 * self.width
+        return self.width * (self.w0_ld or self.n_in) + (self.n_hidden_layers - 1) * self.width * self.width + 16 * self.width
 
     def desc(self) -> MlpDesc:
-        return MlpDesc(self.n_in, self.width, self.n_hidden_layers, self.out_activation, self.in_layout)
+        return MlpDesc(self.n_in, self.width, self.n_hidden_layers, self.out_activation, self.in_layout, self.w0_ld,
+                       self.w0_col, self.w0_mask_col0)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -174,6 +178,21 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
                   ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(te.data_ptr()),
                   _stream())
     return ri, ts, te, packed
+
+
+@torch.no_grad()
+def ray_planes(n_rays: int, device, near_plane: float, far_plane: float, t_min=None, t_max=None, jitter=None,
+               step_size: float = 0.0):
+    """(near_planes[R], far_planes[R]) of R:lse_nerf/lse_grid_estimator.py:83-92 in one launch."""
+    near = torch.empty(n_rays, dtype=torch.float32, device=device)
+    far = torch.empty(n_rays, dtype=torch.float32, device=device)
+    keep = [x for x in (t_min, t_max, jitter) if x is not None]      # (contiguous views stay alive through `keep`)
+    keep = [_c(x.reshape(-1).float()) for x in keep]
+    it = iter(keep)
+    ptrs = [(_f32(next(it), n) if x is not None else None) for x, n in ((t_min, "t_min"), (t_max, "t_max"), (jitter, "jitter"))]
+    _lib.call("lse_ray_planes", float(near_plane), float(far_plane), ptrs[0], ptrs[1], ptrs[2], float(step_size), n_rays,
+              ctypes.c_void_p(near.data_ptr()), ctypes.c_void_p(far.data_ptr()), _stream())
+    return near, far
 
 
 @torch.no_grad()
@@ -481,6 +500,56 @@ class _RayFeaturesFn(torch.autograd.Function):
 def ray_features(rays_d, emb_table=None, emb_idx=None):
     """[R,64] = [SH16 | 15 zeros | emb32 | 1] per ray (tcnn SH-4 of the shifted direction)."""
     return _RayFeaturesFn.apply(rays_d, emb_table, emb_idx)
+
+
+class _RayBiasFn(torch.autograd.Function):
+    """Per-ray share of the head's first layer (lse_ray_bias_fwd / _bwd): directions + embedding rows -> row_bias[R, width].
+    ``head_params`` is the head's tcnn parameter vector; its first width * in_pad floats are W_in[width][in_pad]."""
+
+    @staticmethod
+    def forward(ctx, rays_d, emb_table, emb_idx, head_params, width: int):
+        R = rays_d.shape[0]
+        emb_dim = 0 if emb_table is None else emb_table.shape[1]
+        in_pad = (31 + emb_dim + 15) // 16 * 16
+        dev = rays_d.device
+        feat = torch.empty((R, in_pad), dtype=torch.float32, device=dev)
+        row_bias = torch.empty((R, width), dtype=torch.float32, device=dev)
+        _lib.call("lse_ray_bias_fwd", _f32(rays_d, "rays_d"), _f32(emb_table, "emb_table", True),
+                  _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim, _f32(head_params, "head params"), in_pad, width,
+                  ctypes.c_void_p(feat.data_ptr()), ctypes.c_void_p(row_bias.data_ptr()), _stream())
+        ctx.save_for_backward(rays_d, emb_table, emb_idx, head_params, feat)
+        ctx.width, ctx.in_pad, ctx.emb_dim = width, in_pad, emb_dim
+        return row_bias
+
+    @staticmethod
+    def backward(ctx, d_rb):
+        rays_d, emb_table, emb_idx, head_params, feat = ctx.saved_tensors
+        R, width, in_pad, emb_dim = rays_d.shape[0], ctx.width, ctx.in_pad, ctx.emb_dim
+        d_rb = _c(d_rb)
+        d_feat = torch.empty_like(feat)
+        d_dirs = torch.empty_like(rays_d) if ctx.needs_input_grad[0] else None
+        d_emb = direct_emb = None
+        if emb_table is not None and ctx.needs_input_grad[1] and emb_idx is not None:
+            direct_emb = _direct_grad(emb_table)
+            d_emb = direct_emb if direct_emb is not None else torch.zeros_like(emb_table)
+        _lib.call("lse_ray_bias_bwd", _f32(rays_d, "rays_d"), _chk(emb_idx, torch.int32, "emb_idx", True), R, emb_dim,
+                  0 if emb_table is None else emb_table.shape[0], _f32(head_params, "head params"), in_pad, width,
+                  _f32(d_rb, "d_row_bias"), ctypes.c_void_p(d_feat.data_ptr()), _f32(d_dirs, "d_dirs", True),
+                  _f32(d_emb, "d_emb", True), _stream())
+        d_params = None
+        direct_w = None
+        if ctx.needs_input_grad[3]:
+            direct_w = _direct_grad(head_params)
+            d_params = direct_w if direct_w is not None else torch.zeros_like(head_params)
+            _lib.call("lse_gemm_tn_acc", _f32(d_rb, "d_row_bias"), width, _f32(feat, "feat"), in_pad, _lib.LSE_IN_ROWMAJOR, R,
+                      ctypes.c_void_p(d_params.data_ptr()), in_pad, _stream())
+        return (d_dirs, None if direct_emb is not None else d_emb, None,
+                None if direct_w is not None else d_params, None)
+
+
+def ray_bias(rays_d, emb_table, emb_idx, head_params, width: int):
+    """row_bias[R, width] = [SH16(dir) | 0 x 15 | emb[idx] | 1-padding] @ W_in^T, W_in = the head's tcnn input matrix."""
+    return _RayBiasFn.apply(rays_d, emb_table, emb_idx, head_params, width)
 
 
 class _LinearFn(torch.autograd.Function):

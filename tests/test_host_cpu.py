@@ -64,7 +64,7 @@ def test_argument_counts_match_header():
 def test_descriptor_struct_layouts():
     from lsenerf_amd import _lib
     assert ctypes.sizeof(_lib.GridDesc) == 4 + 4 + 33 * 4 + 32 * 4 + 32 * 4
-    assert ctypes.sizeof(_lib.MlpDesc) == 20
+    assert ctypes.sizeof(_lib.MlpDesc) == 32
 
 
 def test_invalid_arguments_fail_loudly_without_gpu():
