@@ -22,7 +22,7 @@ static Option g_options[] = {
     {"hash_fwd_mapping", {4}},
     {"mlp_fwd_cfg", {28}},
     {"mlp_bwd_cfg", {28}},
-    {"mlp_bwd_share", {1}},
+    {"mlp_bwd_impl", {1}},
     {"traverse_vec", {1}},
 };
 int64_t option(const char *name)

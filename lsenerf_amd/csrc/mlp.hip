@@ -659,6 +659,298 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// backward, second generation: the same mathematics and operand flow as mlp_bwd_kernel<..., WGRAD = true, CT = 2, NW = 8>
+// (fused data + weight gradients, tile-major saved activations), with the vector-instruction overhead around the MFMAs cut:
+//   * every wave walks a CONTIGUOUS range of 32-sample tiles, so all per-tile addresses are "scalar base + small per-lane
+//     offset" (one SALU update per array and tile instead of 64-bit VALU arithmetic per load / store);
+//   * per-row bias gradient (the head's SH + embedding share, lsenerf_amd/field.py) WITHOUT the 16-lane segmented scan
+//     (4 x 16 x {ds_bpermute, v_cndmask, v_add} per column tile = a third of the old kernel's vector instructions):
+//     with the head's first-layer view, input column 0 (the density logit) carries no weight, so its column of the dW0
+//     accumulator tile is free.  Feeding the constant 1 as that input column makes the MFMAs that run anyway accumulate
+//     sum_s dH0[s][m] there -- the bias gradient of the current ray.  Rays are contiguous: the column is flushed (16 atomic
+//     instructions) only when the wave moves on to another ray; a column tile that straddles two rays (one in 64 at 1024
+//     samples per ray) falls back to the scan for that tile alone.  Template parameter BIAS_ONES.
+// ------------------------------------------------------------------------------------------------------
+template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES>
+__global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
+{
+    constexpr int CT = 2, NW = 8, TS = 16 * CT;
+    constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
+    constexpr int RB0 = (KIN + 15) / 16, KB0 = RB0;
+    constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
+    constexpr int NP1 = (NHL - 1) * WIDTH * WIDTH;
+    extern __shared__ float lds[];
+    float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
+    float *tr_all = imgI + IMGI * 64;
+
+    const float *W0 = a.params + a.w0_col;
+    const float *W1 = a.params + a.rest_off;
+    const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
+    for (int e = threadIdx.x; e < IMGO * 64; e += 64 * NW) {
+        const int img = e >> 6, ln = e & 63, rb = img >> 2, ks = img & 3, i = ln & 15, q = ln >> 4;
+        imgO[e] = Wo[(4 * q + ks) * WIDTH + 16 * rb + i];
+    }
+    if (NHL == 2)
+        for (int e = threadIdx.x; e < IMGH * 64; e += 64 * NW) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            imgH[e] = W1[kidx_blk(ks, q) * WIDTH + 16 * rb + i];
+        }
+    if (a.d_in)
+        for (int e = threadIdx.x; e < IMGI * 64; e += 64 * NW) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            const int col = 16 * rb + i;
+            imgI[e] = (col < KIN && !(a.w0_mask0 && col == 0)) ? W0[kidx_blk(ks, q) * a.w0_ld + col] : 0.f;
+        }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    float *tr = tr_all + wave * kTrWave;
+    f32x4 accO[1][HB], acc1[(NHL == 2) ? HB : 1][(NHL == 2) ? HB : 1], acc0[HB][KB0];
+#pragma unroll
+    for (int kb = 0; kb < HB; ++kb) accO[0][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < ((NHL == 2) ? HB : 1); ++mb)
+#pragma unroll
+        for (int kb = 0; kb < ((NHL == 2) ? HB : 1); ++kb) acc1[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t n = a.n;
+    const int64_t n_tiles = (n + TS - 1) / TS;
+    const int64_t total_waves = (int64_t)gridDim.x * NW;
+    const int64_t per = (n_tiles + total_waves - 1) / total_waves;
+    const int64_t w_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t t_begin = min(n_tiles, w_id * per), t_end = min(n_tiles, t_begin + per);
+    const float *act_last = a.act + (int64_t)(NHL - 1) * a.act_layer_stride;
+    const bool need_out = a.out_activation == LSE_ACT_SIGMOID;
+    const int oc = a.out_cols;
+    int cur_row = -1;            // BIAS_ONES: the row whose running sum sits in column 0 of acc0[.][0]
+
+    // column 0 of the dW0 accumulator tile = sum_s dH0[s][m] of row `cur_row`: add it to d_row_bias and clear it
+    auto flush_bias_col = [&]() {
+        if (cur_row >= 0 && j == 0) {
+            float *dst = a.d_row_bias + (int64_t)cur_row * WIDTH + 4 * q;
+#pragma unroll
+            for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dst + 16 * mb + r, acc0[mb][0][r]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[mb][0][r] = (j == 0) ? 0.f : acc0[mb][0][r];
+    };
+
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        __builtin_amdgcn_iglp_opt(0);
+        const int64_t tile_base = tile * TS;
+        const int n_rem = (int)min((int64_t)TS, n - tile_base);       // valid samples of this tile (wave-uniform, >= 1)
+        int sl[CT];                                                    // this lane's sample slot per column tile, clamped
+        bool valid[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            valid[ct] = ct * 16 + j < n_rem;
+            sl[ct] = valid[ct] ? ct * 16 + j : n_rem - 1;
+        }
+        const int act_ct1 = (16 < n_rem) ? 1 : 0;                      // a fully invalid second column tile re-reads the first
+        // per-tile bases (scalar); every access below is base + a per-lane 32-bit offset
+        const float *dout_t = a.d_out + tile_base * oc;
+        const float *out_t = a.out ? a.out + tile_base * oc : nullptr;
+        const float *actl_t = act_last + tile * (CT * HB * 256);
+        const float *act0_t = a.act + tile * (CT * HB * 256);
+
+        f32x4 g[1][CT], ov[CT], hv[HB][CT];
+        float dsg[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if (oc == 16) g[0][ct] = *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(sl[ct] * 16 + 4 * q));
+            else g[0][ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(sl[ct] * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ov[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (need_out) {
+                if (oc == 16) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(sl[ct] * 16 + 4 * q));
+                else if (q == 0) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(sl[ct] * 4));
+            }
+            dsg[ct] = 0.f;
+            if (a.d_sigma && q == 0) {
+                const bool in_bounds = a.selector == nullptr || a.selector[tile_base + sl[ct]] != 0;
+                if (!need_out) ov[ct][0] = out_t[(unsigned)(sl[ct] * oc)];
+                dsg[ct] = in_bounds ? a.d_sigma[tile_base + sl[ct]] : 0.f;
+            }
+            const int cta = ct == 0 ? 0 : act_ct1;
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(actl_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
+        }
+        f32x4 hv0[(NHL == 2) ? HB : 1][CT];
+        if constexpr (NHL == 2) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int cta = ct == 0 ? 0 : act_ct1;
+#pragma unroll
+                for (int rb = 0; rb < HB; ++rb)
+                    hv0[rb][ct] = *reinterpret_cast<const f32x4 *>(act0_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float x0 = fminf(fmaxf(ov[ct][0], -15.f), 15.f);
+            if (need_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[0][ct][r] = g[0][ct][r] * ov[ct][r] * (1.f - ov[ct][r]);
+            }
+            if (a.d_sigma && q == 0) g[0][ct][0] += dsg[ct] * a.density_scale * expf(x0);
+            if (!valid[ct]) g[0][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- output-layer weights
+        wgrad_from_regs<1, HB, CT>(accO, tr, g, hv, j, q);
+        // ---- dH_last
+        f32x4 dh[HB][CT];
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dh[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) {
+                const float aw = imgO[(rb * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) dh[rb][ct] = LSE_MFMA(aw, g[0][ct][r], dh[rb][ct]);
+            }
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[rb][ct][r] > 0.f ? dh[rb][ct][r] : 0.f;
+        // ---- dH_0 (two hidden layers)
+        if constexpr (NHL == 2) {
+            wgrad_from_regs<HB, HB, CT>(acc1, tr, dh, hv0, j, q);
+            f32x4 d0[HB][CT];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) d0[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < HB; ++rb) {
+                        const float aw = imgH[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) d0[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], d0[rb][ct]);
+                    }
+                }
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv0[rb][ct][r] > 0.f ? d0[rb][ct][r] : 0.f;
+        }
+        // ---- layer-0 weights dW0 += dH_0^T * in, and the per-row bias gradient
+        {
+            const float *in_t = (INL == LSE_IN_LEVELMAJOR) ? a.in + tile_base * 2 : a.in + tile_base * KIN;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float ones = 0.f;
+                if (a.d_row_bias) {
+                    const int row = a.row_bias_idx[tile_base + sl[ct]];
+                    if constexpr (BIAS_ONES) {
+                        const int first = __builtin_amdgcn_readfirstlane(row);
+                        if (__builtin_amdgcn_ballot_w64(row != first) == 0) {     // one ray owns this column tile
+                            if (first != cur_row) {
+                                flush_bias_col();
+                                cur_row = first;
+                            }
+                            ones = 1.f;
+                        }
+                    }
+                    if (!BIAS_ONES || ones == 0.f) {                              // straddles two rows: 16-lane segmented scan
+                        f32x4 gcol[HB];
+#pragma unroll
+                        for (int rb = 0; rb < HB; ++rb) gcol[rb] = dh[rb][ct];
+                        row_bias_grad_tile<HB, WIDTH>(a.d_row_bias, row, gcol, j, q);
+                    }
+                }
+                float gb[KB0][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int srow = ct * 16 + 4 * t + q;
+                    srow = srow < n_rem ? srow : n_rem - 1;                       // dH is zero there
+#pragma unroll
+                    for (int kb = 0; kb < KB0; ++kb) {
+                        const int col = 16 * kb + j;
+                        float v = 0.f;
+                        if (col < KIN) {
+                            if (INL == LSE_IN_LEVELMAJOR) v = in_t[((int64_t)(col >> 1) * n + srow) * 2 + (col & 1)];
+                            else v = in_t[(unsigned)(srow * KIN + col)];
+                        }
+                        if (BIAS_ONES && kb == 0) v = (j == 0) ? ones : v;        // the free input column carries the constant
+                        gb[kb][t] = v;
+                    }
+                }
+                f32x4 gblk[HB];
+#pragma unroll
+                for (int mb = 0; mb < HB; ++mb) gblk[mb] = dh[mb][ct];
+                float ga[HB][4];
+                transpose_to_a_operand<HB>(tr, gblk, ga, j, q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+                        for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = LSE_MFMA(ga[mb][t], gb[kb][t], acc0[mb][kb]);
+            }
+        }
+        // ---- dIn
+        if (a.d_in) {
+            f32x4 di[RB0][CT];
+#pragma unroll
+            for (int rb = 0; rb < RB0; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) di[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < RB0; ++rb) {
+                        const float aw = imgI[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) di[rb][ct] = LSE_MFMA(aw, dh[bp][ct][r], di[rb][ct]);
+                    }
+                }
+#pragma unroll
+            for (int rb = 0; rb < RB0; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (!valid[ct] || 16 * rb + 4 * q >= KIN) continue;
+                    if (INL == LSE_IN_LEVELMAJOR) {
+                        float2 *d2 = reinterpret_cast<float2 *>(a.d_in) + tile_base;
+                        const int lv = 8 * rb + 2 * q;
+                        d2[(int64_t)lv * n + sl[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
+                        d2[(int64_t)(lv + 1) * n + sl[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
+                    } else {
+                        *reinterpret_cast<f32x4 *>(a.d_in + tile_base * KIN + (unsigned)(sl[ct] * KIN + 16 * rb + 4 * q)) = di[rb][ct];
+                    }
+                }
+        }
+    }
+    if (BIAS_ONES) flush_bias_col();
+    flush_wgrad<HB, KB0>(a.d_params + a.w0_col, a.w0_ld, KIN, acc0, j, q, a.w0_mask0 != 0);
+    if constexpr (NHL == 2) flush_wgrad<HB, HB>(a.d_params + a.rest_off, WIDTH, WIDTH, acc1, j, q);
+    flush_wgrad<1, HB>(a.d_params + a.rest_off + NP1, WIDTH, WIDTH, accO, j, q);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // weight gradients:  dW[M x K] += G[N x M]^T * A[N x K]   (samples are the MFMA k dimension, so both
 // operands are read straight from their row-major rows: lane (i, q) of k-step s reads row 4s+q, column i)
@@ -814,10 +1106,8 @@ template <int KIN, int WIDTH, int NHL, int INL>
 int launch_fwd(const MlpArgs &a, hipStream_t st)
 {
     const int cfg = (int)lse::option("mlp_fwd_cfg");   // CT*10 + NW
-    switch (cfg) {
+    switch (cfg) {      // (216 / 116 / 24 were measured and dropped in round 1: DESIGN.md section 4.1)
     case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
-    case 216: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
-    case 116: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 1, 16>(a, st);
     default: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
     }
 }
@@ -853,15 +1143,39 @@ int launch_bwd_cfg(const MlpArgs &a, hipStream_t st)
     return lse::check_launch("lse_mlp_bwd");
 }
 
+template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES>
+int launch_bwd2(const MlpArgs &a, hipStream_t st)
+{
+    constexpr int HB = WIDTH / 16, NW = 8;
+    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4);
+    const int64_t tiles = (a.n + 31) / 32;
+    const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);     // one resident workgroup per CU
+    const size_t lds_bytes = imgs * 256 + (size_t)(NW * kTrWave) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds_bytes, hipGetErrorString(e));
+            return LSE_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
+    return lse::check_launch("lse_mlp_bwd");
+}
+
 template <int KIN, int WIDTH, int NHL, int INL>
 int launch_bwd(const MlpArgs &a, hipStream_t st)
 {
     const int cfg = (int)lse::option("mlp_bwd_cfg");   // CT*10 + NW
+    // second-generation kernel: fused weight gradients on tile-major activations, the default tile shape
+    if (a.d_params && a.act_tiled && cfg == 28 && !a.d_out_pre && !a.d_act && !a.d_act0 && lse::option("mlp_bwd_impl") == 1) {
+        if (a.d_row_bias && a.w0_mask0) return launch_bwd2<KIN, WIDTH, NHL, INL, true>(a, st);
+        return launch_bwd2<KIN, WIDTH, NHL, INL, false>(a, st);
+    }
     switch (cfg) {
     case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
-    case 24: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 4>(a, st);
-    case 216: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 16>(a, st);
-    case 116: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 1, 16>(a, st);
     default: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
     }
 }
