@@ -178,6 +178,7 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
  *   "hash_fwd_mapping"  workgroup -> (level, chunk) order of lse_hash_fwd: 4 = level-major, finest level first (default),
  *                       3 = level-major coarse first, 0 / 1 = XCD-bound levels, 2 = level-interleaved
  *   "mlp_fwd_cfg" / "mlp_bwd_cfg"  CT * 10 + NW tile shape of the fused MLP kernels (default 28)
+ *   "mlp_fwd_impl"      1 = second-generation fused forward (contiguous tiles per wave, 4 waves per SIMD; default), 0 = first
  *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
  *                       MFMAs; default), 0 = first-generation kernel
  *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only

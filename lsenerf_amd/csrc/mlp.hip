@@ -263,6 +263,209 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// forward, second generation: the same MFMA chaining as mlp_fwd_kernel<..., CT = 2, NW = 8>, with less vector work around it:
+// contiguous tile range per wave (scalar base + small per-lane offsets for every load / store), integer-max ReLU (one
+// instruction; fmaxf on an MFMA result costs a canonicalising v_max as well), reciprocal-instruction sigmoid, only the
+// per-sample input prefetched one tile ahead (the per-ray bias rows are L2-resident and are fetched at the start of the
+// tile), which keeps the kernel at 4 waves per SIMD: the 1-KiB activation stores of one wave drain under the MFMAs of three
+// others.  Measured at the metric size: head 0.69 -> see DESIGN.md; results are bit-identical to the first generation except
+// for the sigmoid's reciprocal (<= 1 ulp).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float relu_bits(float x)
+{
+    return __int_as_float(max(__float_as_int(x), 0));      // x > 0 ? x : +0 for every non-NaN x (negative floats are negative ints)
+}
+
+__device__ __forceinline__ void store_act(float *p, f32x4 v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<f32x4 *>(p) = v;
+}
+
+template <int KIN, int WIDTH, int NHL, int INL>
+__global__ __launch_bounds__(512) void mlp_fwd2_kernel(MlpArgs a, bool nt)
+{
+    constexpr int CT = 2, NW = 8, TS = 16 * CT;
+    constexpr int HB = WIDTH / 16, KS0 = KIN / 4, KSH = WIDTH / 4;
+    constexpr int IMG0 = HB * KS0, IMGH = (NHL == 2) ? HB * KSH : 0, IMGO = KSH;
+    extern __shared__ float lds[];
+    float *img0 = lds, *imgH = lds + IMG0 * 64, *imgO = imgH + IMGH * 64;
+
+    const float *W0 = a.params + a.w0_col;
+    const float *W1 = a.params + a.rest_off;
+    const float *Wo = W1 + (NHL - 1) * WIDTH * WIDTH;
+    for (int e = threadIdx.x; e < IMG0 * 64; e += 64 * NW) {
+        const int img = e >> 6, ln = e & 63, rb = img / KS0, ks = img % KS0, i = ln & 15, q = ln >> 4;
+        const int c = kidx_in<INL>(ks, q);
+        img0[e] = (a.w0_mask0 && c == 0) ? 0.f : W0[(16 * rb + i) * a.w0_ld + c];
+    }
+    if (NHL == 2)
+        for (int e = threadIdx.x; e < IMGH * 64; e += 64 * NW) {
+            const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
+            imgH[e] = W1[(16 * rb + i) * WIDTH + kidx_blk(ks, q)];
+        }
+    for (int e = threadIdx.x; e < IMGO * 64; e += 64 * NW) {
+        const int ks = e >> 6, ln = e & 63, i = ln & 15, q = ln >> 4;
+        imgO[e] = Wo[i * WIDTH + kidx_blk(ks, q)];
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int64_t n = a.n;
+    const int64_t n_tiles = (n + TS - 1) / TS;
+    const int64_t total_waves = (int64_t)gridDim.x * NW;
+    const int64_t per = (n_tiles + total_waves - 1) / total_waves;
+    const int64_t w_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t t_begin = min(n_tiles, w_id * per), t_end = min(n_tiles, t_begin + per);
+    const int oc = a.out_cols;
+
+    // layer-0 B operands of a tile: breg[ct][ks] = in[sample][kidx_in(ks, q)]
+    auto load_in = [&](int64_t tile, float (&breg)[CT][KS0]) {
+        const int64_t tile_base = tile * TS;
+        const int n_rem = (int)min((int64_t)TS, n - tile_base);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int l = ct * 16 + j;
+            const int slc = l < n_rem ? l : n_rem - 1;
+            if (INL == LSE_IN_LEVELMAJOR) {
+                const float2 *in2 = reinterpret_cast<const float2 *>(a.in) + tile_base;
+#pragma unroll
+                for (int m = 0; m < KIN / 8; ++m) {
+                    const float2 v = in2[(int64_t)(4 * m + q) * n + slc];
+                    breg[ct][2 * m] = v.x;
+                    breg[ct][2 * m + 1] = v.y;
+                }
+            } else {
+                const float *in_t = a.in + tile_base * KIN;
+#pragma unroll
+                for (int b = 0; b < KIN / 16; ++b) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(in_t + (unsigned)(slc * KIN + 16 * b + 4 * q));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) breg[ct][4 * b + r] = v[r];
+                }
+            }
+        }
+    };
+
+    float breg_nx[CT][KS0];
+    if (t_begin < t_end) load_in(t_begin, breg_nx);
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        __builtin_amdgcn_iglp_opt(0);
+        const int64_t tile_base = tile * TS;
+        const int n_rem = (int)min((int64_t)TS, n - tile_base);
+        int sl[CT];
+        bool valid[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            valid[ct] = ct * 16 + j < n_rem;
+            sl[ct] = valid[ct] ? ct * 16 + j : n_rem - 1;
+        }
+        float breg[CT][KS0];
+        f32x4 h[HB][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) breg[ct][ks] = breg_nx[ct][ks];
+        // per-row layer-0 bias = the initial accumulator (rows repeat along a ray: L2 / L1 hits)
+        if (a.row_bias) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[tile_base + sl[ct]] : tile_base + sl[ct];
+#pragma unroll
+                for (int rb = 0; rb < HB; ++rb)
+                    h[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) h[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (tile + 1 < t_end) load_in(tile + 1, breg_nx);
+        // ---- layer 0
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) {
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb) {
+                const float aw = img0[(rb * KS0 + ks) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) h[rb][ct] = LSE_MFMA(aw, breg[ct][ks], h[rb][ct]);
+            }
+        }
+        // tile-major activation image of this tile: [ct][rb][64 lanes][4]; a second column tile beyond n is not stored
+        float *act0_t = a.act ? a.act + tile * (CT * HB * 256) : nullptr;
+        const bool st1 = 16 < n_rem;
+#pragma unroll
+        for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[rb][ct][r] = relu_bits(h[rb][ct][r]);
+                if (act0_t && (ct == 0 || st1)) store_act(act0_t + (unsigned)(((ct * HB + rb) * 64 + lane) * 4), h[rb][ct], nt);
+            }
+        // ---- hidden layer
+        if (NHL == 2) {
+            f32x4 h2[HB][CT];
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ks = 4 * bp + r;
+#pragma unroll
+                    for (int rb = 0; rb < HB; ++rb) {
+                        const float aw = imgH[(rb * KSH + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
+                    }
+                }
+            float *act1_t = act0_t ? act0_t + a.act_layer_stride : nullptr;
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[rb][ct][r] = relu_bits(h2[rb][ct][r]);
+                    if (act1_t && (ct == 0 || st1)) store_act(act1_t + (unsigned)(((ct * HB + rb) * 64 + lane) * 4), h[rb][ct], nt);
+                }
+        }
+        // ---- output layer
+        f32x4 o[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bp = 0; bp < HB; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float aw = imgO[(4 * bp + r) * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) o[ct] = LSE_MFMA(aw, h[bp][ct][r], o[ct]);
+            }
+        float *out_t = a.out + tile_base * oc;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if (a.out_activation == LSE_ACT_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[ct][r] = __builtin_amdgcn_rcpf(1.f + __expf(-o[ct][r]));
+            }
+            if (valid[ct]) {
+                if (oc == 16) *reinterpret_cast<f32x4 *>(out_t + (unsigned)(sl[ct] * 16 + 4 * q)) = o[ct];
+                else if (q == 0) *reinterpret_cast<f32x4 *>(out_t + (unsigned)(sl[ct] * 4)) = o[ct];
+                if (a.sigma_out && q == 0) {
+                    const bool in_bounds = a.selector == nullptr || a.selector[tile_base + sl[ct]] != 0;
+                    a.sigma_out[tile_base + sl[ct]] = in_bounds ? a.density_scale * expf(o[ct][0]) : 0.f;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // backward:  dOut -> dH_last -> (dH_0) -> dIn chained in registers with transposed A images, and (WGRAD) the weight
 // gradients of every layer in the same pass.
@@ -746,6 +949,43 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
             for (int r = 0; r < 4; ++r) acc0[mb][0][r] = (j == 0) ? 0.f : acc0[mb][0][r];
     };
 
+    // raw operands of one tile: output gradient, output values (activation / density backward), last-layer activations
+    auto fetch = [&](int64_t tile, f32x4 (&g)[1][CT], f32x4 (&ov)[CT], float (&dsg)[CT], f32x4 (&hv)[HB][CT]) {
+        const int64_t tile_base = tile * TS;
+        const int n_rem = (int)min((int64_t)TS, n - tile_base);
+        const float *dout_t = a.d_out + tile_base * oc;
+        const float *out_t = a.out ? a.out + tile_base * oc : nullptr;
+        const float *actl_t = act_last + tile * (CT * HB * 256);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int l = ct * 16 + j;
+            const int slc = l < n_rem ? l : n_rem - 1;
+            if (oc == 16) g[0][ct] = *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(slc * 16 + 4 * q));
+            else g[0][ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(slc * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ov[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (need_out) {
+                if (oc == 16) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 16 + 4 * q));
+                else if (q == 0) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 4));
+            }
+            dsg[ct] = 0.f;
+            if (a.d_sigma && q == 0) {
+                const bool in_bounds = a.selector == nullptr || a.selector[tile_base + slc] != 0;
+                if (!need_out) ov[ct][0] = out_t[(unsigned)(slc * oc)];
+                dsg[ct] = in_bounds ? a.d_sigma[tile_base + slc] : 0.f;
+            }
+            const int cta = (ct == 0 || 16 >= n_rem) ? 0 : 1;       // a fully invalid second column tile re-reads the first
+#pragma unroll
+            for (int rb = 0; rb < HB; ++rb)
+                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(actl_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
+        }
+    };
+    // one tile ahead where the registers allow it (single hidden layer): two waves per SIMD alone do not hide the HBM
+    // latency of the activation / gradient loads (measured: 48 % of the wave cycles in s_waitcnt without it)
+    constexpr bool PF = (NHL == 1);
+    f32x4 g_n[1][CT], ov_n[CT], hv_n[HB][CT];
+    float dsg_n[CT];
+    if (PF && t_begin < t_end) fetch(t_begin, g_n, ov_n, dsg_n, hv_n);
+
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         __builtin_amdgcn_iglp_opt(0);
         const int64_t tile_base = tile * TS;
@@ -757,34 +997,22 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
             valid[ct] = ct * 16 + j < n_rem;
             sl[ct] = valid[ct] ? ct * 16 + j : n_rem - 1;
         }
-        const int act_ct1 = (16 < n_rem) ? 1 : 0;                      // a fully invalid second column tile re-reads the first
-        // per-tile bases (scalar); every access below is base + a per-lane 32-bit offset
-        const float *dout_t = a.d_out + tile_base * oc;
-        const float *out_t = a.out ? a.out + tile_base * oc : nullptr;
-        const float *actl_t = act_last + tile * (CT * HB * 256);
+        const int act_ct1 = (16 < n_rem) ? 1 : 0;
         const float *act0_t = a.act + tile * (CT * HB * 256);
-
         f32x4 g[1][CT], ov[CT], hv[HB][CT];
         float dsg[CT];
+        if constexpr (PF) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            if (oc == 16) g[0][ct] = *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(sl[ct] * 16 + 4 * q));
-            else g[0][ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(sl[ct] * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            ov[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (need_out) {
-                if (oc == 16) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(sl[ct] * 16 + 4 * q));
-                else if (q == 0) ov[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(sl[ct] * 4));
-            }
-            dsg[ct] = 0.f;
-            if (a.d_sigma && q == 0) {
-                const bool in_bounds = a.selector == nullptr || a.selector[tile_base + sl[ct]] != 0;
-                if (!need_out) ov[ct][0] = out_t[(unsigned)(sl[ct] * oc)];
-                dsg[ct] = in_bounds ? a.d_sigma[tile_base + sl[ct]] : 0.f;
-            }
-            const int cta = ct == 0 ? 0 : act_ct1;
+            for (int ct = 0; ct < CT; ++ct) {
+                g[0][ct] = g_n[0][ct];
+                ov[ct] = ov_n[ct];
+                dsg[ct] = dsg_n[ct];
 #pragma unroll
-            for (int rb = 0; rb < HB; ++rb)
-                hv[rb][ct] = *reinterpret_cast<const f32x4 *>(actl_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
+                for (int rb = 0; rb < HB; ++rb) hv[rb][ct] = hv_n[rb][ct];
+            }
+            if (tile + 1 < t_end) fetch(tile + 1, g_n, ov_n, dsg_n, hv_n);
+        } else {
+            fetch(tile, g, ov, dsg, hv);
         }
         f32x4 hv0[(NHL == 2) ? HB : 1][CT];
         if constexpr (NHL == 2) {
@@ -795,6 +1023,32 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                 for (int rb = 0; rb < HB; ++rb)
                     hv0[rb][ct] = *reinterpret_cast<const f32x4 *>(act0_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
             }
+        }
+        // layer-0 input in B-operand layout for dW0 (lane (j, q), k-step t: in[sample 4t+q][column 16kb+j]), requested now so
+        // that its latency hides under the MFMA chain below (single hidden layer; the two-layer kernel has no registers left)
+        constexpr bool EARLY_IN = (NHL == 1);
+        float gbe[EARLY_IN ? CT : 1][KB0][4];
+        auto load_gb = [&](int ct, float (&gb)[KB0][4]) {
+            const float *in_t = (INL == LSE_IN_LEVELMAJOR) ? a.in + tile_base * 2 : a.in + tile_base * KIN;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int srow = ct * 16 + 4 * t + q;
+                srow = srow < n_rem ? srow : n_rem - 1;                       // dH is zero there
+#pragma unroll
+                for (int kb = 0; kb < KB0; ++kb) {
+                    const int col = 16 * kb + j;
+                    float v = 0.f;
+                    if (col < KIN) {
+                        if (INL == LSE_IN_LEVELMAJOR) v = in_t[((int64_t)(col >> 1) * n + srow) * 2 + (col & 1)];
+                        else v = in_t[(unsigned)(srow * KIN + col)];
+                    }
+                    gb[kb][t] = v;
+                }
+            }
+        };
+        if constexpr (EARLY_IN) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) load_gb(ct, gbe[ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -857,7 +1111,6 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
         }
         // ---- layer-0 weights dW0 += dH_0^T * in, and the per-row bias gradient
         {
-            const float *in_t = (INL == LSE_IN_LEVELMAJOR) ? a.in + tile_base * 2 : a.in + tile_base * KIN;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 float ones = 0.f;
@@ -881,21 +1134,17 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                     }
                 }
                 float gb[KB0][4];
+                if constexpr (EARLY_IN) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    int srow = ct * 16 + 4 * t + q;
-                    srow = srow < n_rem ? srow : n_rem - 1;                       // dH is zero there
+                    for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
-                    for (int kb = 0; kb < KB0; ++kb) {
-                        const int col = 16 * kb + j;
-                        float v = 0.f;
-                        if (col < KIN) {
-                            if (INL == LSE_IN_LEVELMAJOR) v = in_t[((int64_t)(col >> 1) * n + srow) * 2 + (col & 1)];
-                            else v = in_t[(unsigned)(srow * KIN + col)];
-                        }
-                        if (BIAS_ONES && kb == 0) v = (j == 0) ? ones : v;        // the free input column carries the constant
-                        gb[kb][t] = v;
-                    }
+                        for (int t = 0; t < 4; ++t) gb[kb][t] = gbe[ct][kb][t];
+                } else {
+                    load_gb(ct, gb);
+                }
+                if constexpr (BIAS_ONES) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gb[0][t] = (j == 0) ? ones : gb[0][t];   // the free input column carries the constant
                 }
                 f32x4 gblk[HB];
 #pragma unroll
@@ -1106,6 +1355,15 @@ template <int KIN, int WIDTH, int NHL, int INL>
 int launch_fwd(const MlpArgs &a, hipStream_t st)
 {
     const int cfg = (int)lse::option("mlp_fwd_cfg");   // CT*10 + NW
+    if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") == 1) {
+        constexpr int HB2 = WIDTH / 16;
+        constexpr int imgs2 = HB2 * (KIN / 4) + (NHL == 2 ? HB2 * (WIDTH / 4) : 0) + WIDTH / 4;
+        const int64_t tiles2 = (a.n + 31) / 32;
+        const int blocks2 = (int)std::min<int64_t>((tiles2 + 7) / 8, 512);      // two resident workgroups per CU
+        hipLaunchKernelGGL((mlp_fwd2_kernel<KIN, WIDTH, NHL, INL>), dim3(blocks2), dim3(512), imgs2 * 256, st, a,
+                           lse::option("mlp_act_nt") != 0);
+        return lse::check_launch("lse_mlp_fwd");
+    }
     switch (cfg) {      // (216 / 116 / 24 were measured and dropped in round 1: DESIGN.md section 4.1)
     case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
     default: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
