@@ -115,6 +115,14 @@ int lse_ray_planes(float near_plane, float far_plane, const float *t_min, const 
 int lse_visibility_mask(const float *t_starts, const float *t_ends, const float *sigmas,
                         const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
                         uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
+/* Survivors of the visibility culling keep what the sigma_fn pre-pass computed for them: x01[N,3], selector[N] and the
+ * level-major hash features y[L][N][2] (F = 2) are compacted with the same mask / packed_info pair as
+ * lse_compact_samples, so the main field pass does not encode them again (R:lse_nerf/lse_grid_estimator.py:109-143 evaluates
+ * the field twice on every survivor). */
+int lse_compact_features(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info, int32_t n_rays,
+                         const float *x01, const uint8_t *selector, const float *y, int32_t n_levels, int64_t n_old,
+                         int64_t n_new, float *out_x01, uint8_t *out_selector, float *out_y, lse_stream_t stream);
+
 /* nerfacc.render_visibility_from_alpha (the alpha_fn branch, R:lse_nerf/lse_grid_estimator.py:128-138): same scan on
  * per-sample opacities; T_k = prod_{i<k} (1 - alpha_i), mask = T >= early_stop_eps && alpha >= alpha_thre. */
 int lse_visibility_mask_alpha(const float *alphas, const int64_t *packed_info, int32_t n_rays, float early_stop_eps,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
     "lse_visibility_mask_alpha": [P, P, I32, F32, F32, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
+    "lse_compact_features": [P, P, P, I32, P, P, P, I32, I64, I64, P, P, P, P],
     "lse_positions_fwd": [P, P, P, P, P, I64, I32, P, P, P, P],
     "lse_positions_bwd": [P, P, P, P, P, I64, I32, P, P, P, P],
     "lse_ray_grad_reduce": [P, P, P, P, I32, P, P, P],

@@ -233,7 +233,62 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
     }
 }
 
+// The visibility pre-pass has already encoded every candidate sample (unit-cube position, selector, hash features); the
+// survivors of the culling keep theirs instead of being encoded a second time by the main pass: same per-ray ballot /
+// popcount compaction as compact_kernel, applied to x01[N,3], selector[N] and the level-major features y[L][N][2]
+// (a wave's 64 lanes read 512 contiguous bytes per level).  256 B moved per survivor against 1024 B gathered by a re-encode.
+__global__ __launch_bounds__(256) void compact_features_kernel(const uint8_t *__restrict__ mask, const int64_t *__restrict__ packed,
+                                                               const int64_t *__restrict__ new_packed, int n_rays,
+                                                               const float *__restrict__ x01, const uint8_t *__restrict__ sel,
+                                                               const float2 *__restrict__ y, int n_levels, int64_t n_old,
+                                                               int64_t n_new, float *__restrict__ o_x01,
+                                                               uint8_t *__restrict__ o_sel, float2 *__restrict__ o_y)
+{
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
+    int64_t dst = new_packed[2 * ray];
+    for (int64_t base = 0; base < cnt; base += 64) {
+        const int64_t i = s0 + base + lane;
+        const bool keep = (base + lane < cnt) && mask[i];
+        const unsigned long long bal = __ballot(keep);
+        const int64_t o = dst + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            o_x01[o * 3 + 0] = x01[i * 3 + 0];
+            o_x01[o * 3 + 1] = x01[i * 3 + 1];
+            o_x01[o * 3 + 2] = x01[i * 3 + 2];
+            o_sel[o] = sel[i];
+            int l = 0;
+            for (; l + 8 <= n_levels; l += 8) {        // 8 independent loads in flight, then 8 stores
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = y[(int64_t)(l + u) * n_old + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o_y[(int64_t)(l + u) * n_new + o] = v[u];
+            }
+            for (; l < n_levels; ++l) o_y[(int64_t)l * n_new + o] = y[(int64_t)l * n_old + i];
+        }
+        dst += __popcll(bal);
+    }
+}
+
 }  // namespace
+
+extern "C" int lse_compact_features(const uint8_t *mask, const int64_t *packed_info, const int64_t *new_packed_info,
+                                    int32_t n_rays, const float *x01, const uint8_t *selector, const float *y,
+                                    int32_t n_levels, int64_t n_old, int64_t n_new, float *out_x01,
+                                    uint8_t *out_selector, float *out_y, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0 && n_old >= 0 && n_new >= 0 && n_levels >= 1, "lse_compact_features: bad sizes");
+    if (n_rays == 0 || n_new == 0) return LSE_OK;
+    LSE_REQUIRE(mask && packed_info && new_packed_info && x01 && selector && y && out_x01 && out_selector && out_y,
+                "lse_compact_features: null pointer");
+    hipLaunchKernelGGL(compact_features_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), mask, packed_info,
+                       new_packed_info, n_rays, x01, selector, reinterpret_cast<const float2 *>(y), n_levels, n_old, n_new,
+                       out_x01, out_selector, reinterpret_cast<float2 *>(out_y));
+    return lse::check_launch("lse_compact_features");
+}
 
 extern "C" int lse_volrend_fwd(const float *t_starts, const float *t_ends, const float *sigmas, const float *rgb,
                                int32_t rgb_stride, const int64_t *packed_info, int32_t n_rays, float *weights,

@@ -299,6 +299,8 @@ class LSEField(nn.Module):
         self.mlp_head = MLP(in_dim=16 + geo_feat_dim + self.appearance_embedding_dim, num_layers=num_layers_color,
                             layer_width=hidden_dim_color, out_dim=3, out_activation="Sigmoid")
         self._aabb6 = None
+        self.reuse_prepass = True  # the main pass re-uses the visibility pre-pass's positions / hash features of the survivors
+        self._prepass = None
         self._h_ref = None        # weak reference to the last base-MLP output (get_density -> get_outputs hand-over)
 
     # -- helpers ---------------------------------------------------------------------------------------
@@ -312,21 +314,74 @@ class LSEField(nn.Module):
         return ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction,
                              None if contraction else self._aabb_list())
 
-    def density_packed(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info
-                       ) -> Tuple[Tensor, Tensor, Tensor]:
-        """Fast path of get_density on packed samples: returns (sigma[N], h[N,16] base-MLP output, selector[N])."""
-        x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
-        n = x01.shape[0]
-        y = self.mlp_base_grid.forward_levelmajor(x01)
+    def prepass_sigma_fn(self, origins: Tensor, directions: Tensor) -> Callable:
+        """``sigma_fn`` of the sampler's visibility pre-pass (nerfstudio VolumetricSampler.get_sigma_fn) on packed samples.
+        The returned callable also has ``on_cull``: the estimator calls it with the visibility mask, and the positions /
+        selector / hash features the pre-pass computed for the SURVIVING samples are compacted and parked on the field, where
+        the main pass of the same step picks them up (``density_packed``) instead of encoding those samples again
+        (``reuse_prepass``; the reference evaluates hash grid + base MLP twice on every survivor)."""
+        fld = self
+        state = {}
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            ri = ray_indices if ray_indices.dtype == torch.int32 else ray_indices.to(torch.int32)
+            with torch.no_grad():
+                x01, sel = fld._x01(origins, directions, ri, t_starts, t_ends, None)
+                y = fld.mlp_base_grid.forward_levelmajor(x01)
+                sigma = fld._base_mlp(y, sel, x01.shape[0])[1]
+            state.update(x01=x01, sel=sel, y=y)
+            return sigma
+
+        def on_cull(mask, packed_info, new_packed_info, new_ray_indices, new_t_starts, new_t_ends):
+            if not (fld.reuse_prepass and state):
+                return
+            n_new = new_t_starts.shape[0]
+            x01, sel, y = ops.compact_features(mask, packed_info, new_packed_info, n_new, state["x01"], state["sel"], state["y"])
+            state.clear()
+            # keyed on the survivors' own buffers (kept alive here, so the addresses cannot be recycled) and the ray bundle
+            fld._prepass = {"key": (new_t_starts.data_ptr(), new_ray_indices.data_ptr(), n_new, origins.data_ptr(),
+                                    directions.data_ptr()),
+                            "hold": (new_t_starts, new_ray_indices, new_t_ends), "x01": x01, "sel": sel, "y": y,
+                            "version": fld.mlp_base_grid.params._version}
+
+        sigma_fn.on_cull = on_cull
+        return sigma_fn
+
+    def _base_mlp(self, y: Tensor, sel: Tensor, n: int):
+        """(h[N,16], sigma[N]) = base MLP on level-major hash features with the fused trunc_exp density head."""
         mlp = self.mlp_base_mlp
         dens = (sel, self.average_init_density)    # trunc_exp density head fused into the MLP epilogue / backward
         if mlp.in_pad == mlp.in_dim:
-            h, sigma = ops.fused_mlp(mlp.params, y, mlp.meta(), n, density=dens)
-        else:   # small grids (L*F < 16): tcnn's ones-padding columns act as a bias shared by every sample
-            kparams, bias = mlp.split_padding()
-            idx = torch.zeros(n, dtype=torch.int32, device=x01.device)
-            seg = torch.tensor([[0, n]], dtype=torch.int64, device=x01.device)
-            h, sigma = ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg, density=dens)
+            return ops.fused_mlp(mlp.params, y, mlp.meta(), n, density=dens)
+        # small grids (L*F < 16): tcnn's ones-padding columns act as a bias shared by every sample
+        kparams, bias = mlp.split_padding()
+        idx = torch.zeros(n, dtype=torch.int32, device=y.device)
+        seg = torch.tensor([[0, n]], dtype=torch.int64, device=y.device)
+        return ops.fused_mlp(kparams, y, mlp.meta(mlp.in_dim), n, bias, idx, seg, density=dens)
+
+    def _take_prepass(self, rays_o, rays_d, ray_idx, t_starts):
+        """The parked pre-pass features if they belong to exactly these samples and these parameters, else None."""
+        pp, self._prepass = self._prepass, None
+        if pp is None or ray_idx is None or rays_d is None:
+            return None
+        key = (t_starts.data_ptr(), ray_idx.data_ptr(), t_starts.shape[0], rays_o.data_ptr(), rays_d.data_ptr())
+        if key != pp["key"] or pp["version"] != self.mlp_base_grid.params._version:
+            return None
+        return pp
+
+    def density_packed(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info
+                       ) -> Tuple[Tensor, Tensor, Tensor]:
+        """Fast path of get_density on packed samples: returns (sigma[N], h[N,16] base-MLP output, selector[N])."""
+        pp = self._take_prepass(rays_o, rays_d, ray_idx, t_starts) if t_starts is not None else None
+        if pp is not None:   # survivors of this step's visibility pre-pass: positions + hash features are already there
+            x01, sel = ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, self._contraction == "inf",
+                                     None if self._contraction == "inf" else self._aabb_list(), precomputed=(pp["x01"], pp["sel"]))
+            y = ops.hash_encode(x01, self.mlp_base_grid.params, self.mlp_base_grid.meta, precomputed=pp["y"])
+            h, sigma = self._base_mlp(y, sel, x01.shape[0])
+            return sigma, h, sel
+        x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
+        y = self.mlp_base_grid.forward_levelmajor(x01)
+        h, sigma = self._base_mlp(y, sel, x01.shape[0])
         return sigma, h, sel
 
     def rgb_packed(self, h: Tensor, rays_d: Tensor, emb_idx: Optional[Tensor], ray_idx: Optional[Tensor],

@@ -102,8 +102,12 @@ class LSEOccGridEstimator(nn.Module):
                 with torch.no_grad():
                     sigmas = sigma_fn(t_starts, t_ends, ray_indices)
                 assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
-                ray_indices, t_starts, t_ends, packed_info, _ = ops.visibility_compact(
+                old_packed = packed_info
+                ray_indices, t_starts, t_ends, packed_info, mask = ops.visibility_compact(
                     ray_indices, t_starts, t_ends, sigmas.contiguous(), packed_info, early_stop_eps, alpha_thre)
+                on_cull = getattr(sigma_fn, "on_cull", None)      # the field keeps the survivors' pre-pass features
+                if on_cull is not None and t_starts.shape[0] > 0:
+                    on_cull(mask, old_packed, packed_info, ray_indices, t_starts, t_ends)
             else:
                 with torch.no_grad():
                     alphas = alpha_fn(t_starts, t_ends, ray_indices)

@@ -147,10 +147,10 @@ class VolumetricSampler(nn.Module):
         if self.density_fn is None or not self.training:
             return None
         density_fn, fld = self.density_fn, self._packed_field
+        if fld is not None:
+            return fld.prepass_sigma_fn(origins, directions)
 
         def sigma_fn(t_starts, t_ends, ray_indices):
-            if fld is not None:
-                return fld.density_packed(origins, directions, ray_indices.to(torch.int32), t_starts, t_ends, None)[0]
             ri = ray_indices.long()
             positions = origins[ri] + directions[ri] * (t_starts + t_ends)[:, None] / 2.0
             if times is None:

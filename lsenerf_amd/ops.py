@@ -243,16 +243,22 @@ def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early
 # ----------------------------------------------------------------------------------------------------
 class _PositionsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction: bool, aabb6):
+    def forward(ctx, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction: bool, aabb6, pre=None):
         direct = ray_idx is None
         n = rays_o.shape[0] if direct else ray_idx.shape[0]
-        x01 = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device)
-        sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
-        aabb_arr = (ctypes.c_float * 6)(*aabb6) if aabb6 is not None else None
-        _lib.call("lse_positions_fwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
-                  _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
-                  _f32(t_ends, "t_ends", True), n, int(contraction), aabb_arr, ctypes.c_void_p(x01.data_ptr()),
-                  ctypes.c_void_p(sel.data_ptr()), _stream())
+        if pre is not None:     # (x01, selector) already computed for exactly these samples by the visibility pre-pass
+            x01, sel = pre
+            assert x01.shape == (n, 3) and sel.shape == (n,)
+            x01 = x01.detach().view_as(x01)     # fresh tensor objects: outputs of this node
+            sel = sel.view_as(sel)
+        else:
+            x01 = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device)
+            sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
+            aabb_arr = (ctypes.c_float * 6)(*aabb6) if aabb6 is not None else None
+            _lib.call("lse_positions_fwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
+                      _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
+                      _f32(t_ends, "t_ends", True), n, int(contraction), aabb_arr, ctypes.c_void_p(x01.data_ptr()),
+                      ctypes.c_void_p(sel.data_ptr()), _stream())
         ctx.save_for_backward(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
         ctx.contraction, ctx.aabb6, ctx.n = contraction, aabb6, n
         ctx.mark_non_differentiable(sel)
@@ -270,7 +276,7 @@ class _PositionsFn(torch.autograd.Function):
                   _f32(t_ends, "t_ends", True), n, int(ctx.contraction), aabb_arr, _f32(d_x01, "d_x01"),
                   ctypes.c_void_p(d_pos.data_ptr()), _stream())
         if ray_idx is None:
-            return d_pos, None, None, None, None, None, None, None
+            return d_pos, None, None, None, None, None, None, None, None
         if packed_info is None:
             raise _lib.LseHipError("positions backward w.r.t. rays needs packed_info")
         R = rays_o.shape[0]
@@ -280,13 +286,14 @@ class _PositionsFn(torch.autograd.Function):
             _lib.call("lse_ray_grad_reduce", ctypes.c_void_p(d_pos.data_ptr()), _f32(t_starts, "t_starts"),
                       _f32(t_ends, "t_ends"), _chk(packed_info, torch.int64, "packed_info"), R,
                       _f32(d_o, "d_o", True), _f32(d_d, "d_d", True), _stream())
-        return d_o, d_d, None, None, None, None, None, None
+        return d_o, d_d, None, None, None, None, None, None, None
 
 
-def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction=True, aabb6=None):
+def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction=True, aabb6=None, precomputed=None):
     """Sample positions in the field's unit cube + in-bounds selector (R:lse_nerf/lse_field.py:266-274).
-    ``ray_idx is None``: ``rays_o`` holds positions directly (Field.density_fn)."""
-    return _PositionsFn.apply(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction, aabb6)
+    ``ray_idx is None``: ``rays_o`` holds positions directly (Field.density_fn).  ``precomputed = (x01, selector)``: values
+    the visibility pre-pass already produced for exactly these samples (only the autograd node is created)."""
+    return _PositionsFn.apply(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction, aabb6, precomputed)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -304,12 +311,16 @@ def _direct_grad(p: torch.Tensor):
 
 class _HashFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x01, table, meta: GridMeta):
+    def forward(ctx, x01, table, meta: GridMeta, pre_y=None):
         n = x01.shape[0]
-        y = torch.empty((meta.n_levels, n, meta.n_features), dtype=torch.float32, device=x01.device)
-        desc = meta.desc()
-        _lib.call("lse_hash_fwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(table, "table"),
-                  ctypes.c_void_p(y.data_ptr()), n, _stream())
+        if pre_y is not None:      # features of exactly these positions, encoded by the visibility pre-pass with this table
+            assert pre_y.shape == (meta.n_levels, n, meta.n_features)
+            y = pre_y.detach().view_as(pre_y)
+        else:
+            y = torch.empty((meta.n_levels, n, meta.n_features), dtype=torch.float32, device=x01.device)
+            desc = meta.desc()
+            _lib.call("lse_hash_fwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(table, "table"),
+                      ctypes.c_void_p(y.data_ptr()), n, _stream())
         ctx.save_for_backward(x01, table)
         ctx.meta = meta
         return y
@@ -336,13 +347,30 @@ class _HashFn(torch.autograd.Function):
         else:
             _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
                       ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
-        return dx, (None if direct is not None else dtable), None
+        return dx, (None if direct is not None else dtable), None, None
 
 
-def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta) -> torch.Tensor:
+def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta, precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tcnn HashGrid forward.  Returns level-major features y[L, N, F] (the fused MLP consumes this directly);
-    ``y.permute(1, 0, 2).reshape(N, L*F)`` is the [N, L*F] tensor tcnn's torch binding returns."""
-    return _HashFn.apply(x01, table, meta)
+    ``y.permute(1, 0, 2).reshape(N, L*F)`` is the [N, L*F] tensor tcnn's torch binding returns.
+    ``precomputed``: y already encoded for exactly these positions with this table (only the autograd node is created)."""
+    return _HashFn.apply(x01, table, meta, precomputed)
+
+
+@torch.no_grad()
+def compact_features(mask, packed_info, new_packed_info, n_new: int, x01, sel, y):
+    """(x01, selector, y) of the ``n_new`` samples that survive ``mask`` (lse_compact_features); y is level-major [L, N, 2]."""
+    R = packed_info.shape[0]
+    n_old, L = x01.shape[0], y.shape[0]
+    dev = x01.device
+    o_x = torch.empty((n_new, 3), dtype=torch.float32, device=dev)
+    o_s = torch.empty(n_new, dtype=torch.uint8, device=dev)
+    o_y = torch.empty((L, n_new, 2), dtype=torch.float32, device=dev)
+    _lib.call("lse_compact_features", _chk(mask, torch.uint8, "mask"), _chk(packed_info, torch.int64, "packed_info"),
+              _chk(new_packed_info, torch.int64, "new_packed_info"), R, _f32(x01, "x01"), _chk(sel, torch.uint8, "selector"),
+              _f32(y, "y"), L, n_old, n_new, ctypes.c_void_p(o_x.data_ptr()), ctypes.c_void_p(o_s.data_ptr()),
+              ctypes.c_void_p(o_y.data_ptr()), _stream())
+    return o_x, o_s, o_y
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -179,3 +179,60 @@ def test_flat_params_receive_gradients_in_place_and_adam_matches_oracle():
         assert nmax_err(flat.data, ref_p.detach()) < 1e-5
         with torch.no_grad():
             ref_p.copy_(flat.data)
+
+
+def test_main_pass_reuses_the_prepass_features_of_the_survivors():
+    """Default configuration: the visibility pre-pass encodes every candidate; the survivors' unit-cube positions, selector and
+    hash features are compacted (lse_compact_features) and picked up by the main pass instead of a second hash forward.
+    Outputs and every gradient must be those of the path that encodes twice (bitwise for the forward: same kernels, same
+    inputs), and the hand-over must refuse anything but exactly the samples / parameters it was made for."""
+    from lsenerf_amd import _lib
+    hip, _ = make_model_pair(grid_levels=2, grid_resolution=32, occupied_frac=0.5, param_scale=300.0, emb_type="evs_emb")
+    hip.train()
+    o, d = random_rays(200, seed=21)
+    aid = torch.randint(0, 8, (200,), generator=torch.Generator().manual_seed(2)).cuda()
+    jit = torch.rand(200, generator=torch.Generator().manual_seed(3)).cuda()
+    res = {}
+    calls = {}
+    orig_call = _lib.call
+
+    def counting_call(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig_call(name, *a)
+
+    for reuse in (True, False):
+        hip.field.reuse_prepass = reuse
+        og, dg = o.clone().cuda().requires_grad_(True), d.clone().cuda().requires_grad_(True)
+        rb = _bundle(og, dg, metadata={"appearance_id": aid})
+        rb.origins, rb.directions = og, dg
+        for p in hip.parameters():
+            p.grad = None
+        calls.clear()
+        _lib.call = counting_call
+        try:
+            out = hip.exec_get_outputs(rb, jitter=jit)
+        finally:
+            _lib.call = orig_call
+        n_hash_fwd = calls.get("lse_hash_fwd", 0)
+        assert n_hash_fwd == (1 if reuse else 2), (reuse, calls)
+        assert calls.get("lse_compact_features", 0) == (1 if reuse else 0)
+        (out["rgb"].sum() + out["depth"].sum() + out["accumulation"].sum()).backward()
+        res[reuse] = (out, {n: p.grad.clone() for n, p in hip.named_parameters() if p.grad is not None}, og.grad.clone(), dg.grad.clone())
+        assert hip.field._prepass is None            # consumed
+    a, b = res[True], res[False]
+    assert int(a[0]["num_samples_per_ray"].sum()) > 1000
+    for k in ("rgb", "depth", "accumulation", "num_samples_per_ray"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    for n in a[1]:
+        assert nmax_err(a[1][n], b[1][n], 1e-12) < TOL_GRAD, n           # float atomics: not bitwise
+    assert nmax_err(a[2], b[2], 1e-12) < TOL_GRAD and nmax_err(a[3], b[3], 1e-12) < TOL_GRAD
+    # the hand-over is keyed: other samples, or parameters that changed in between, do not take it
+    hip.field.reuse_prepass = True
+    rb = _bundle(o.clone().cuda(), d.clone().cuda(), metadata={"appearance_id": aid})
+    rs, _ = hip.sampler(ray_bundle=rb, near_plane=0.05, far_plane=1e3, render_step_size=hip.config.render_step_size,
+                        alpha_thre=0.01, cone_angle=0.004, jitter=jit)
+    assert hip.field._prepass is not None
+    with torch.no_grad():
+        hip.field.mlp_base_grid.params.mul_(1.0)       # in-place update bumps the version: features are stale
+    ts, te = rs.frustums.starts[..., 0], rs.frustums.ends[..., 0]
+    assert hip.field._take_prepass(rb.origins, rb.directions, rs.ray_indices, ts) is None
