@@ -164,10 +164,12 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
                         int64_t n, lse_stream_t stream);
 
 /* Kernel selection of the hash backward as CALL ARGUMENTS (so that two variants can be compared inside one process):
- *   impl          1 = lane-per-sample kernel with the per-wave LDS sector cache (default); 0 = 16-lanes-per-sample kernel
+ *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
+ *                     levels batched into one cache pass (default); 1 = one cache pass per level; 0 = 16-lanes-per-sample kernel
+ *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 16)
  *   gran          cache slot size of impl 1: 2 = 32-B sectors x 512 slots (default), 3 = 64-B lines x 256 slots
- *   few_runs      impl 1: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
- *   second_probe  impl 1: probe the neighbouring slot before falling back to memory (default 0)
+ *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 4)
+ *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)
  *   dbg           timing experiments only (bit 0: skip flush atomics, bit 1: skip run ends, bit 2: skip the scan) -> WRONG results
@@ -175,6 +177,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
 typedef struct lse_hash_bwd_opts {
     int32_t impl, gran, few_runs, second_probe, rounds, dbg;
     float interleave_from_scale;
+    int32_t stage_max;
 } lse_hash_bwd_opts;
 void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
 int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,

@@ -26,7 +26,7 @@ class GridDesc(Structure):
 
 class HashBwdOpts(Structure):
     _fields_ = [("impl", c_int32), ("gran", c_int32), ("few_runs", c_int32), ("second_probe", c_int32), ("rounds", c_int32),
-                ("dbg", c_int32), ("interleave_from_scale", c_float)]
+                ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32)]
 
 
 class EpilogueDesc(Structure):

@@ -665,6 +665,340 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
     }
 }
 
+template <bool WITH_DX, int kSlots, int kEntLog2>
+__global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
+                                                              const float2 *__restrict__ dy,
+                                                              const float2 *__restrict__ table,
+                                                              float *__restrict__ dtable, float *__restrict__ dx,
+                                                              int64_t n, int dbg, int few_runs, int second_probe, int stage_max)
+{
+    constexpr int kRounds = 1;                 // one 64-sample round per wave
+    constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
+    constexpr int kPay = 2 * kEnt;             // payload floats per slot = lanes per slot in the flush
+    constexpr int kSlotBits = 31 - __builtin_clz((unsigned)kSlots);
+    constexpr int kChunk = 64 * kRounds;
+    __shared__ uint32_t s_key[4][kSlots];
+    __shared__ float s_val[4][kSlots * kPay];
+    __shared__ uint16_t s_list[4][kSlots];      // occupied slots
+    __shared__ uint32_t s_dummy32[4][64];
+    __shared__ uint64_t s_dummy64[4][64];
+    __shared__ uint32_t s_perm[4][64];          // rank -> lane of the run ends being staged
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
+    if (wave_base >= n) return;
+    lds_u32 *key = (lds_u32 *)&s_key[wave][0];
+    lds_f32 *val = (lds_f32 *)&s_val[wave][0];
+    lds_u16 *list = (lds_u16 *)&s_list[wave][0];
+    lds_u32 *dummy32 = (lds_u32 *)&s_dummy32[wave][lane];
+    lds_u64 *dummy64 = (lds_u64 *)&s_dummy64[wave][lane];
+    lds_u32 *perm = (lds_u32 *)&s_perm[wave][0];
+    *dummy32 = kNoLine;
+    *dummy64 = 0;
+    for (int s = lane; s < kSlots; s += 64) key[s] = kNoLine;
+    for (int s = lane; s < kSlots * kPay; s += 64) val[s] = 0.f;
+
+    float px[kRounds][3], dacc[kRounds][3];
+    int64_t si[kRounds];
+    bool valid[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int64_t i = wave_base + r * 64 + lane;
+        valid[r] = i < n;
+        si[r] = valid[r] ? i : n - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            px[r][d] = x[si[r] * 3 + d];
+            dacc[r][d] = 0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the cache is private to this wave; DS ops of a wave execute in order
+
+    // ---- register queue of run ends waiting for a cache pass: lane t < fill holds one run end (8 GLOBAL entry indices =
+    // level offset + index inside the level, and its 8 x 2 corner sums).  Cache keys are global sector ids, so run ends of
+    // several levels share one pass: the insert + flush below costs ~0.1 ms per pass at the metric size however few lanes
+    // take part (measured: 1.5 of the kernel's 2.9 ms), and the levels 4 .. 9 end only 5 .. 15 runs per wave each.
+    uint32_t q_idx[8];
+    float q_v[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) q_idx[c] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q_v[k] = 0.f;
+    int fill = 0;
+
+    auto insert_pass = [&](const bool act, const uint32_t (&gi)[8], const float (&vv)[16]) {
+        uint32_t used = 0;   // occupied cache slots (wave-uniform)
+            if (__builtin_amdgcn_ballot_w64(act) != 0) {
+                // multiplicative hash of the line id (a slot function linear in the cell coordinates was tried: more
+                // collisions on ray-shaped line sets, tools/sim_hash_bwd_requests.py)
+                uint32_t slot[8], old[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) slot[c] = (__umul24(gi[c] >> kEntLog2, 0x9E3779u) >> (24 - kSlotBits)) & (kSlots - 1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (gi[c] >> kEntLog2) : kNoLine);
+                // float LDS atomics run at ~3 cycles per LANE on gfx950 (tools/micro/lds_ops.hip: ds_add_f32 194 cycles
+                // per instruction, ds_cmpst_b64 22): add both features with one 64-bit compare-and-swap
+                lds_u64 *va[8];
+                bool to_mem[8], okc[8];
+                uint64_t cur[8], prev[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool claim = act && old[c] == kNoLine;
+                    const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                    if (cm) {
+                        if (claim)
+                            list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                (uint16_t)slot[c];
+                        used += __builtin_popcountll(cm);
+                    }
+                    okc[c] = claim || (act && old[c] == (gi[c] >> kEntLog2));
+                    to_mem[c] = act && !okc[c];
+                }
+                for (int pr = 0; pr < second_probe; ++pr) {
+                    // another chance in the next slot for the corners that lost the previous one (batched the same way)
+                    bool any = false;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) any = any || to_mem[c];
+                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                        uint32_t old2[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + 1) & (kSlots - 1)] : dummy32, kNoLine,
+                                              to_mem[c] ? (gi[c] >> kEntLog2) : kNoLine);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const bool claim = to_mem[c] && old2[c] == kNoLine;
+                            const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                            if (cm) {
+                                if (claim)
+                                    list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                        (uint16_t)((slot[c] + 1) & (kSlots - 1));
+                                used += __builtin_popcountll(cm);
+                            }
+                            if (claim || (to_mem[c] && old2[c] == (gi[c] >> kEntLog2))) {
+                                slot[c] = (slot[c] + 1) & (kSlots - 1);
+                                okc[c] = true;
+                                to_mem[c] = false;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    va[c] = okc[c] ? (lds_u64 *)&val[slot[c] * kPay + (gi[c] & (kEnt - 1)) * 2] : dummy64;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cur[c] = *va[c];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) prev[c] = lds_cas(va[c], cur[c], add_pair(cur[c], vv[2 * c], vv[2 * c + 1]));
+                bool retry = false;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) retry = retry || prev[c] != cur[c];
+                if (__builtin_amdgcn_ballot_w64(retry) != 0) {   // rare: two lanes (or two corners of a lane) on one entry
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        while (prev[c] != cur[c]) {
+                            cur[c] = prev[c];
+                            prev[c] = lds_cas(va[c], cur[c], add_pair(cur[c], vv[2 * c], vv[2 * c + 1]));
+                        }
+                }
+                // Corners whose slot is owned by another sector go straight to memory.  The two features of an entry are
+                // written by a PAIR of lanes in one instruction (lane and lane^1 swap operands through DPP), so the
+                // 8 bytes cost one request to the atomic units instead of two.
+                const bool is_odd = lane & 1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (__builtin_amdgcn_ballot_w64(to_mem[c]) == 0) continue;
+                    const uint32_t gi_n = (uint32_t)quad_swap1((int)gi[c]);
+                    const float v0_n = __int_as_float(quad_swap1(__float_as_int(vv[2 * c])));
+                    const float v1_n = __int_as_float(quad_swap1(__float_as_int(vv[2 * c + 1])));
+                    const bool tm_n = quad_swap1((int)to_mem[c]) != 0;
+                    // first instruction serves the even lanes' corners, second one the odd lanes'
+                    if (is_odd ? tm_n : to_mem[c]) atomicAdd(dtable + 2 * (size_t)(is_odd ? gi_n : gi[c]) + is_odd, is_odd ? v1_n : vv[2 * c]);
+                    if (is_odd ? to_mem[c] : tm_n) atomicAdd(dtable + 2 * (size_t)(is_odd ? gi[c] : gi_n) + is_odd, is_odd ? vv[2 * c + 1] : v0_n);
+                }
+            }
+            // flush: 16 lanes per line, 4 lines per instruction, 16 lines per trip (loads first)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int kPer = 64 / kPay;   // slots per flush instruction
+            const int sub = lane & (kPay - 1);
+            for (uint32_t e0 = lane / kPay; e0 < used; e0 += 4 * kPer) {
+                uint32_t ent[4], ln[4];
+                float vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ent[u] = (e0 + kPer * u < used) ? (uint32_t)list[e0 + kPer * u] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ln[u] = (ent[u] != 0xFFFFFFFFu) ? key[ent[u]] : 0u;
+                    vv[u] = (ent[u] != 0xFFFFFFFFu) ? val[ent[u] * kPay + sub] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (vv[u] != 0.f && !(dbg & 1)) atomicAdd(dtable + (size_t)ln[u] * kPay + sub, vv[u]);
+                __builtin_amdgcn_wave_barrier();   // every lane of a slot has read the key before lane 0 resets it
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ent[u] != 0xFFFFFFFFu) {
+                        val[ent[u] * kPay + sub] = 0.f;
+                        if (sub == 0) key[ent[u]] = kNoLine;
+                    }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int l = g.l_begin; l < g.l_end; ++l) {
+        const LevelInfo li = level_info(g, l);
+        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;      // (few-runs path only)
+        const float2 *__restrict__ tab = table + li.offset;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            float w0, w1, w2;
+            uint32_t p0, p1, p2;
+            pos_fract(px[r][0], li.scale, w0, p0);
+            pos_fract(px[r][1], li.scale, w1, p1);
+            pos_fract(px[r][2], li.scale, w2, p2);
+            float2 gy = dy[(int64_t)l * n + si[r]];
+            if (!valid[r]) gy = make_float2(0.f, 0.f);
+            uint32_t idx[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) idx[c] = grid_index(li, p0 + (c & 1), p1 + ((c >> 1) & 1), p2 + ((c >> 2) & 1));
+            float2 tv[8];
+            if (WITH_DX) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
+            }
+            // runs of lanes in the same cell
+            const uint32_t q0 = __shfl_up(p0, 1), q1 = __shfl_up(p1, 1), q2 = __shfl_up(p2, 1);
+            const int head = (lane == 0) || (q0 != p0) || (q1 != p1) || (q2 != p2);
+            const int next_head = __shfl_down(head, 1);
+            const bool run_end = (lane == 63) || next_head;
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
+                v[2 * c] = wt * gy.x;
+                v[2 * c + 1] = wt * gy.y;
+            }
+            if (!(dbg & 4)) {
+                // segmented inclusive scan: inside the 16-lane rows with DPP, then a serial carry across the 3 row borders
+                const int row_pos = lane & 15;
+                int flag = head | (row_pos == 0);   // "my partial sum already starts at my run's head (or my row's start)"
+                if (seg_scan_row_step<1>(v, flag, row_pos) && seg_scan_row_step<2>(v, flag, row_pos) &&
+                    seg_scan_row_step<4>(v, flag, row_pos))
+                    seg_scan_row_step<8>(v, flag, row_pos);
+                // `open` = no run head between my row's first lane and me (inclusive): my run continues from the row before
+                int open = !head;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const int o = (off == 1) ? row_shr_i32<1>(open) : (off == 2) ? row_shr_i32<2>(open)
+                                : (off == 4) ? row_shr_i32<4>(open) : row_shr_i32<8>(open);
+                    open &= (row_pos >= off) ? o : 1;
+                }
+                seg_scan_cross_rows(v, open, lane);
+            }
+            if (WITH_DX) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float sx = (c & 1) ? w0 : 1.f - w0, sy = (c & 2) ? w1 : 1.f - w1, sz = (c & 4) ? w2 : 1.f - w2;
+                    const float t = li.scale * (gy.x * tv[c].x + gy.y * tv[c].y);
+                    dacc[r][0] += t * ((c & 1) ? 1.f : -1.f) * (sy * sz);
+                    dacc[r][1] += t * ((c & 2) ? 1.f : -1.f) * (sx * sz);
+                    dacc[r][2] += t * ((c & 4) ? 1.f : -1.f) * (sx * sy);
+                }
+            }
+            // ---- run ends add their 8 corner sums into the line cache, then the level's lines are flushed.
+            // The kernel is instruction-issue bound (rocprof: VALU+SALU+LDS issue ~ 3 ms of a 3.6 ms launch), so this part
+            // is written for few instructions: one probe per corner, no retry rounds (a lost slot goes straight to memory),
+            // every DS operation issued by all lanes (idle lanes aim at a private dummy word) so that a batch of 8 goes out
+            // back to back with one wait.
+            const uint64_t ends_mask = __builtin_amdgcn_ballot_w64(run_end && !(dbg & 2));
+            const int n_ends = __builtin_popcountll(ends_mask);
+            if (n_ends <= few_runs) {
+                // Coarse levels: a wave ends only a handful of runs, and almost all of the ~500 instructions of the cache
+                // path below would be spent on idle lanes.  Instead the run ends park their 8 indices + 16 sums in LDS
+                // (the zeroed payload area doubles as staging) and the wave re-reads them with 16 lanes per run -- lane =
+                // (corner, feature), 4 runs per instruction -- and adds straight to memory: the two features and the
+                // x / x+1 neighbours of an entry share requests inside the instruction.
+                if (n_ends > 0) {
+                    lds_u32 *stage = (lds_u32 *)val;           // [run][8 idx | 16 values]
+                    if (run_end && !(dbg & 2)) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0));
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) stage[rank * 24 + c] = idx[c];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) stage[rank * 24 + 8 + k] = __float_as_uint(v[k]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int k16 = lane & 15;
+                    for (int r0 = lane >> 4; r0 < n_ends; r0 += 4) {
+                        const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
+                        const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
+                        if (a != 0.f) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int s_ = lane; s_ < n_ends * 24; s_ += 64) stage[s_] = 0u;   // the payload area must read zero again
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                uint32_t gidx[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gidx[c] = li.offset + idx[c];
+                if (fill + n_ends > 64) {               // the queue cannot take this level: run the pending pass first
+                    insert_pass(lane < fill, q_idx, q_v);
+                    fill = 0;
+                }
+                if (fill == 0 && n_ends > stage_max) {
+                    // fine level: most lanes end a run -- pass straight from the lanes that hold them (no compaction)
+                    insert_pass(run_end && !(dbg & 2), gidx, v);
+                } else {
+                    // append: queue lane fill + r takes the r-th run end of this level (rank -> lane through LDS, then 24
+                    // ds_bpermute moves); the pass runs when the queue is full, at a fine level, or after the last level
+                    if (run_end && !(dbg & 2))
+                        perm[__builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0))] = (uint32_t)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int r = lane - fill;
+                    const bool take = r >= 0 && r < n_ends;
+                    const int src = take ? (int)perm[r] : lane;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)gidx[c]);
+                        q_idx[c] = take ? t : q_idx[c];
+                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v[k2])));
+                        q_v[k2] = take ? t : q_v[k2];
+                    }
+                    fill += n_ends;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (fill > 0) insert_pass(lane < fill, q_idx, q_v);
+    if (WITH_DX) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+            if (valid[r]) {
+                if (g.dx_accumulate) {
+                    dacc[r][0] += dx[si[r] * 3 + 0];
+                    dacc[r][1] += dx[si[r] * 3 + 1];
+                    dacc[r][2] += dx[si[r] * 3 + 2];
+                }
+                dx[si[r] * 3 + 0] = dacc[r][0];
+                dx[si[r] * 3 + 1] = dacc[r][1];
+                dx[si[r] * 3 + 2] = dacc[r][2];
+            }
+    }
+}
+
+
 int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
 {
     LSE_REQUIRE(desc, "%s: null desc", who);
@@ -708,10 +1042,12 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
 extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
 {
     if (!o) return;
-    o->impl = 1;           // lane-per-sample + LDS sector cache
+    o->impl = 2;           // lane-per-sample + LDS sector cache, run ends of several levels batched per cache pass
+    o->stage_max = 16;     // impl 2: a level ending more runs than this per wave passes unstaged when the queue is empty
     o->gran = 2;           // 512 slots of one 32-B sector
-    o->few_runs = 6;       // tuned on MI355X: 4..8 equal, 16 already slower
-    o->second_probe = 0;
+    o->few_runs = 4;       // tuned on MI355X: 4..8 equal, 16 already slower
+    o->second_probe = 1;   // extra probe rounds (next slot) before a corner goes to memory alone; pays wherever the kernel is
+                           // bound by atomic requests (sphere rays 4.27 -> 3.86 ms), costs ~2 % where it is issue-bound
     o->rounds = 32;
     o->dbg = 0;
     o->interleave_from_scale = 1e30f;   // measured negative on MI355X (same-address lanes of one atomic instruction serialise)
@@ -737,7 +1073,8 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     lse_hash_bwd_opts o;
     lse_hash_bwd_default_opts(&o);
     if (opts) o = *opts;
-    LSE_REQUIRE(o.impl == 0 || o.impl == 1, "lse_hash_bwd: opts.impl must be 0 or 1");
+    LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
+    LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
     LSE_REQUIRE(o.gran == 2 || o.gran == 3, "lse_hash_bwd: opts.gran must be 2 or 3");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
@@ -761,7 +1098,18 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
     bool lines_ok = true;
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
-    if (impl == 1 && lines_ok) {
+    if (impl == 2 && lines_ok) {     // per-wave sector cache with run ends of several levels batched into one pass
+        const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
+        LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
+        const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
+        const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                   tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+        else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+        return lse::check_launch("lse_hash_bwd");
+    }
+    if (impl >= 1 && lines_ok) {
         const int few_runs = o.few_runs, second_probe = o.second_probe, gran = o.gran;
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
