@@ -7,7 +7,7 @@ ks = glob.glob(f'gpurun_out/{tag}/prof/*/*kernel_stats.csv')[0]
 shutil.copy(ks, f'profiles/{pre}_bench_kernel_stats.csv')
 shutil.copy(f'gpurun_out/{tag}/bench.log', f'profiles/{pre}_bench.log')
 rows = list(csv.DictReader(open(ks)))
-steps = 7   # gpu_round.sh profiles bench.py --steps 5 --warmup 2
+steps = 12   # gpu_round.sh profiles bench.py --steps 5 --warmup 2 (+ 5 steps of the instrumented breakdown pass)
 for r in rows[:30]:
     print(f"{r['Name'][:88]:88s} calls={r['Calls']:>5s} ms/step={float(r['TotalDurationNs'])/1e6/steps:8.3f} avg_us={float(r['AverageNs'])/1e3:9.1f}")
 print("total kernel ms/step", sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / steps, " kernels/step", sum(int(r['Calls']) for r in rows) / steps)
@@ -27,9 +27,9 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
         out.setdefault(k, {})[C] = sum(v) / len(v)
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1].get('FETCH_SIZE', 0) + kv[1].get('WRITE_SIZE', 0)))[:6]:
     print(f"{k:32s} fetch_kib={v.get('FETCH_SIZE',0):12.0f} write_kib={v.get('WRITE_SIZE',0):12.0f} GB={(v.get('FETCH_SIZE',0)+v.get('WRITE_SIZE',0))*1024/1e9:.3f}")
-hb = out.get('hash_bwd_cached_kernel') or out['hash_bwd_kernel']
+hb = out.get('hash_bwd_batched_kernel') or out.get('hash_bwd_cached_kernel') or out['hash_bwd_kernel']
 hf = out['hash_fwd_kernel']
 j = {"_comment": f"HBM-side traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only), run {pre} (profiles/{pre}_pmc_*.csv). Counter values are KiB: bytes = (FETCH_SIZE + WRITE_SIZE) * 1024. gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads exactly 1/2 for wide (16 B/lane) streaming reads and is UNCALIBRATED for the 4-8 B gathers these kernels issue, so the fetch side is a lower bound; WRITE_SIZE is exact for float atomics and 16-B stores.",
      "lse_hash_fwd": {"fetch_kib": round(hf['FETCH_SIZE']), "write_kib": round(hf['WRITE_SIZE']), "bytes": round((hf['FETCH_SIZE'] + hf['WRITE_SIZE']) * 1024)},
-     "lse_hash_bwd": {"kernel": "hash_bwd_cached_kernel<true,512,2>", "fetch_kib": round(hb['FETCH_SIZE']), "write_kib": round(hb['WRITE_SIZE']), "bytes": round((hb['FETCH_SIZE'] + hb['WRITE_SIZE']) * 1024)}}
+     "lse_hash_bwd": {"kernel": "hash_bwd_batched_kernel<true,512,2>", "fetch_kib": round(hb['FETCH_SIZE']), "write_kib": round(hb['WRITE_SIZE']), "bytes": round((hb['FETCH_SIZE'] + hb['WRITE_SIZE']) * 1024)}}
 json.dump(j, open('profiles/pmc_traffic.json', 'w'), indent=1)
