@@ -153,6 +153,45 @@ def vectorized_generalized_interpolation(control_poses: Tensor, control_ts: Tens
 # ----------------------------------------------------------------------------------------------------
 # cameras
 # ----------------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# lens distortion (OpenCV radial-tangential model, as nerfstudio's camera_utils applies it at R:lse_nerf/lse_cameras.py:396-413)
+# ----------------------------------------------------------------------------------------------------
+def radial_and_tangential_distort(xy: Tensor, params: Tensor) -> Tensor:
+    """Forward model: ideal normalised image coordinates [...,2] -> distorted ones; params [...,6] = (k1,k2,k3,k4,p1,p2)."""
+    k1, k2, k3, k4, p1, p2 = [params[..., i] for i in range(6)]
+    x, y = xy[..., 0], xy[..., 1]
+    r = x * x + y * y
+    d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+    return torch.stack([d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x), d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y)], -1)
+
+
+def radial_and_tangential_undistort(coords: Tensor, distortion_params: Tensor, eps: float = 1e-3,
+                                    max_iterations: int = 10) -> Tensor:
+    """Inverse of the model above by Newton iterations on the 2x2 system (10 steps from the distorted point, a step is
+    skipped where the Jacobian determinant is below ``eps``) -- the scheme the reference inherits from nerfstudio 0.3.2.
+    coords [...,2]; distortion_params broadcastable [...,6]."""
+    k1, k2, k3, k4, p1, p2 = [distortion_params[..., i] for i in range(6)]
+    xd, yd = coords[..., 0], coords[..., 1]
+    x, y = xd.clone(), yd.clone()
+    for _ in range(max_iterations):
+        r = x * x + y * y
+        d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+        fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+        fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+        d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+        d_x, d_y = 2.0 * x * d_r, 2.0 * y * d_r
+        fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+        fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+        fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+        fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+        det = fy_x * fx_y - fx_x * fy_y
+        ok = det.abs() > eps
+        safe = torch.where(ok, det, torch.ones_like(det))
+        x = x + torch.where(ok, (fx * fy_y - fy * fx_y) / safe, torch.zeros_like(det))
+        y = y + torch.where(ok, (fy * fx_x - fx * fy_x) / safe, torch.zeros_like(det))
+    return torch.stack([x, y], -1)
+
+
 class HardCamType:
     RGB = 0
     EVS = 1
@@ -164,8 +203,11 @@ class EdCameras:
     of intrinsics for all cameras (:359-362)."""
 
     def __init__(self, camera_to_worlds: Tensor, fx: float, fy: float, cx: float, cy: float, width: int, height: int,
-                 times: Optional[Tensor] = None, metadata: Optional[Dict[str, Tensor]] = None):
+                 times: Optional[Tensor] = None, metadata: Optional[Dict[str, Tensor]] = None,
+                 distortion_params: Optional[Tensor] = None):
         self.camera_to_worlds = camera_to_worlds.float()          # [C,3,4]
+        # (k1,k2,k3,k4,p1,p2) for all cameras ([6]) or per camera ([C,6]); None / all zero = pinhole
+        self.distortion_params = distortion_params.float() if distortion_params is not None else None
         self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
         self.width, self.height = int(width), int(height)
         self.times = times.float().reshape(-1, 1) if times is not None else None
@@ -194,8 +236,8 @@ class EdCameras:
         ys, xs = torch.meshgrid(torch.arange(self.height), torch.arange(self.width), indexing="ij")
         return torch.stack([ys, xs], -1).float()
 
-    def generate_rays(self, camera_indices: Tensor, coords: Tensor, camera_opt_to_camera: Optional[Tensor] = None
-                      ) -> RayBundle:
+    def generate_rays(self, camera_indices: Tensor, coords: Tensor, camera_opt_to_camera: Optional[Tensor] = None,
+                      disable_distortion: bool = False) -> RayBundle:
         """camera_indices [R] (or [R,1]); coords [R,2] = (y, x) pixels.  Perspective model, OpenGL camera frame
         (x right, y up, looking down -z).  R:lse_nerf/lse_cameras.py:340-586."""
         c2w = self.get_c2w_fn(camera_indices)                      # [R,3,4]
@@ -205,9 +247,16 @@ class EdCameras:
         dev = c2w.device
         y, x = coords[..., 0].to(dev).float(), coords[..., 1].to(dev).float()
 
-        def cam_dir(xx, yy):
-            return torch.stack([(xx - self.cx) / self.fx, -(yy - self.cy) / self.fy, -torch.ones_like(xx)], -1)
-        stack = torch.stack([cam_dir(x, y), cam_dir(x + 1, y), cam_dir(x, y + 1)], 0)              # [3,R,3]
+        def cam_xy(xx, yy):
+            return torch.stack([(xx - self.cx) / self.fx, -(yy - self.cy) / self.fy], -1)
+        xy = torch.stack([cam_xy(x, y), cam_xy(x + 1, y), cam_xy(x, y + 1)], 0)                    # [3,R,2]
+        dist = self.distortion_params
+        if dist is not None and not disable_distortion and bool((dist != 0).any()):                 # R:lse_cameras.py:396-413
+            dist = dist.to(dev)
+            if dist.dim() == 2:
+                dist = dist[camera_indices.reshape(-1).long().to(dev)]
+            xy = radial_and_tangential_undistort(xy, dist.expand(xy.shape[:-1] + (6,)))
+        stack = torch.cat([xy, -torch.ones_like(xy[..., :1])], -1)                                  # [3,R,3]
         world = torch.sum(stack[..., None, :] * c2w[None, :, :3, :3], dim=-1)                       # rotate
         norm = torch.linalg.norm(world, dim=-1, keepdim=True)
         world = world / norm

@@ -175,7 +175,7 @@ class CameraSetReader:
                          cx=cx, cy=cy, width=w, height=h,
                          times=torch.tensor(times, dtype=torch.float32) if times is not None else None)
         cams.set_hard_cam_type(cam_type)
-        cams.distortion_params = None if float(dist.sum()) == 0 else dist
+        cams.distortion_params = None if float(dist.sum()) == 0 else dist     # applied by EdCameras.generate_rays
         return (cams, dM) if calc_dm else cams
 
     def relative_event_camera(self, w2cs: np.ndarray, colmap_scale: float) -> torch.Tensor:

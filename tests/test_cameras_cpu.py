@@ -245,3 +245,34 @@ def test_event_ray_generators():
     cams.set_interpolator(spl)
     rb4 = cam.DeblurRayGenerator(cams)(idx)
     assert len(rb4) == 12 and rb4.camera_indices.reshape(-1).tolist() == [0] * 4 + [4] * 4 + [2] * 4
+
+
+def test_lens_distortion_is_applied_and_inverts_the_forward_model():
+    """R:lse_nerf/lse_cameras.py:396-413: rays of a camera with (k1,k2,k3,k4,p1,p2) != 0 go through the iterative
+    radial-tangential undistortion.  Independent check: distort ideal points with the closed-form forward model, undistort
+    them, recover the originals; and a distorted camera's ray through a distorted pixel equals the pinhole ray through the
+    ideal pixel."""
+    g = torch.Generator().manual_seed(0)
+    ideal = (torch.rand(500, 2, generator=g, dtype=torch.float64) - 0.5) * 1.2
+    params = torch.tensor([-0.12, 0.05, -0.01, 0.0, 0.002, -0.003], dtype=torch.float64)
+    distorted = cam.radial_and_tangential_distort(ideal, params.expand(500, 6))
+    assert float((distorted - ideal).abs().max()) > 1e-3
+    back = cam.radial_and_tangential_undistort(distorted, params.expand(500, 6))
+    assert float((back - ideal).abs().max()) < 1e-9
+    # through the cameras
+    cams, c2w, ts = _cameras()
+    dcams = cam.EdCameras(torch.from_numpy(c2w), cams.fx, cams.fy, cams.cx, cams.cy, cams.width, cams.height,
+                          times=torch.from_numpy(ts), distortion_params=params.float())
+    px_ideal = torch.tensor([[100.0, 500.0], [400.0, 50.0], [240.0, 320.0]])           # (y, x)
+    xy_i = torch.stack([(px_ideal[:, 1] - cams.cx) / cams.fx, -(px_ideal[:, 0] - cams.cy) / cams.fy], -1)
+    xy_d = cam.radial_and_tangential_distort(xy_i.double(), params.expand(3, 6)).float()
+    px_dist = torch.stack([cams.cy - xy_d[:, 1] * cams.fy, xy_d[:, 0] * cams.fx + cams.cx], -1)
+    ci = torch.tensor([1, 4, 7])
+    want = cams.generate_rays(ci, px_ideal)
+    got = dcams.generate_rays(ci, px_dist)
+    assert torch.allclose(got.directions, want.directions, atol=2e-6) and torch.allclose(got.origins, want.origins)
+    raw = dcams.generate_rays(ci, px_dist, disable_distortion=True)
+    assert float((raw.directions - want.directions).abs().max()) > 1e-4
+    assert torch.allclose(cams.generate_rays(ci, px_ideal).directions,
+                          cam.EdCameras(torch.from_numpy(c2w), cams.fx, cams.fy, cams.cx, cams.cy, cams.width, cams.height,
+                                        distortion_params=torch.zeros(6)).generate_rays(ci, px_ideal).directions)
