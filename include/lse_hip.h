@@ -200,7 +200,10 @@ int lse_get_option(const char *name, int64_t *value);
 /* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
  * [n_hidden_layers][N][width] (what lse_mlp_wgrad reads); act_tiled = 1 -> tile-major, an opaque workspace of
- * n_hidden_layers * roundup(N,16) * width floats that only lse_mlp_bwd (same act_tiled) understands.
+ * n_hidden_layers * roundup(N,16) * width floats that only lse_mlp_bwd (same act_tiled) understands; act_tiled = 2 (two
+ * hidden layers, row-major input): tile-major WITHOUT the first hidden layer ((n_hidden_layers - 1) * roundup(N,16) * width
+ * floats) -- lse_mlp_bwd recomputes it from `in` and `row_bias` (32 extra MFMAs per 32 samples against 2 KiB per sample of
+ * activation traffic), bit-identical to what the forward computed.
  * out is [N,16] (out_cols = 16) or the compact [N,4] holding outputs 0..3 (out_cols = 4, e.g. rgb).
  * sigma_out (nullable): fused density head sigma[N] = density_scale * exp(out[:,0]) * selector (trunc_exp,
  * R:lse_nerf/lse_field.py:286-287); selector nullable. */
@@ -217,7 +220,7 @@ int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, 
 int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, int32_t act_tiled,
                 const float *out, int32_t out_cols, const float *d_out, const float *d_sigma, const uint8_t *selector, float density_scale,
                 float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params,
-                const int32_t *row_bias_idx, float *d_row_bias, int64_t n, lse_stream_t stream);
+                const float *row_bias, const int32_t *row_bias_idx, float *d_row_bias, int64_t n, lse_stream_t stream);
 /* unfused weight gradients from materialised d_act / d_out_pre, accumulate into d_params (same layout as params). */
 int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
                   const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream);

@@ -67,7 +67,7 @@ SIGNATURES = {
     "lse_set_option": [c_char_p, I64],
     "lse_get_option": [c_char_p, POINTER(c_int64)],
     "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
-    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, I64, P],
+    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, P, I64, P],
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
     "lse_segment_sum_rows": [P, I32, P, I32, P, P],
     "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],

@@ -398,13 +398,14 @@ __global__ __launch_bounds__(512) void mlp_fwd2_kernel(MlpArgs a, bool nt)
         // tile-major activation image of this tile: [ct][rb][64 lanes][4]; a second column tile beyond n is not stored
         float *act0_t = a.act ? a.act + tile * (CT * HB * 256) : nullptr;
         const bool st1 = 16 < n_rem;
+        const bool skip0 = NHL == 2 && a.act_tiled == 2;      // the backward recomputes the first hidden layer
 #pragma unroll
         for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[rb][ct][r] = relu_bits(h[rb][ct][r]);
-                if (act0_t && (ct == 0 || st1)) store_act(act0_t + (unsigned)(((ct * HB + rb) * 64 + lane) * 4), h[rb][ct], nt);
+                if (act0_t && !skip0 && (ct == 0 || st1)) store_act(act0_t + (unsigned)(((ct * HB + rb) * 64 + lane) * 4), h[rb][ct], nt);
             }
         // ---- hidden layer
         if (NHL == 2) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(512) void mlp_fwd2_kernel(MlpArgs a, bool nt)
                         for (int ct = 0; ct < CT; ++ct) h2[rb][ct] = LSE_MFMA(aw, h[bp][ct][r], h2[rb][ct]);
                     }
                 }
-            float *act1_t = act0_t ? act0_t + a.act_layer_stride : nullptr;
+            float *act1_t = act0_t ? act0_t + (skip0 ? 0 : a.act_layer_stride) : nullptr;
 #pragma unroll
             for (int rb = 0; rb < HB; ++rb)
 #pragma unroll
@@ -876,17 +877,22 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
 //     instructions) only when the wave moves on to another ray; a column tile that straddles two rays (one in 64 at 1024
 //     samples per ray) falls back to the scan for that tile alone.  Template parameter BIAS_ONES.
 // ------------------------------------------------------------------------------------------------------
-template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES>
+//   * RECOMP (two hidden layers, row-major input): the forward did not save the first hidden layer (act_tiled = 2); it is
+//     recomputed here from the layer-0 input and the per-row bias -- the same MFMA chain in the same k order, so the values
+//     are bit-identical to the forward's -- at 32 extra MFMAs per tile against 1 KiB x 8 of activations written and read.
+template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES, bool RECOMP = false>
 __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
 {
     constexpr int CT = 2, NW = 8, TS = 16 * CT;
-    constexpr int HB = WIDTH / 16, KSH = WIDTH / 4;
+    constexpr int HB = WIDTH / 16, KSH = WIDTH / 4, KS0 = KIN / 4;
     constexpr int RB0 = (KIN + 15) / 16, KB0 = RB0;
-    constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH;
+    constexpr int IMGO = HB * 4, IMGH = (NHL == 2) ? HB * KSH : 0, IMGI = RB0 * KSH, IMG0 = RECOMP ? HB * KS0 : 0;
     constexpr int NP1 = (NHL - 1) * WIDTH * WIDTH;
+    static_assert(!RECOMP || (NHL == 2 && INL == LSE_IN_ROWMAJOR && KIN % 16 == 0), "recompute: two hidden layers, row-major input");
     extern __shared__ float lds[];
     float *imgO = lds, *imgH = lds + IMGO * 64, *imgI = imgH + IMGH * 64;
-    float *tr_all = imgI + IMGI * 64;
+    float *img0 = imgI + IMGI * 64;                           // forward image of W0 (RECOMP only)
+    float *tr_all = img0 + IMG0 * 64;
 
     const float *W0 = a.params + a.w0_col;
     const float *W1 = a.params + a.rest_off;
@@ -905,6 +911,12 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
             const int img = e >> 6, ln = e & 63, rb = img / KSH, ks = img % KSH, i = ln & 15, q = ln >> 4;
             const int col = 16 * rb + i;
             imgI[e] = (col < KIN && !(a.w0_mask0 && col == 0)) ? W0[kidx_blk(ks, q) * a.w0_ld + col] : 0.f;
+        }
+    if constexpr (RECOMP)
+        for (int e = threadIdx.x; e < IMG0 * 64; e += 64 * NW) {
+            const int img = e >> 6, ln = e & 63, rb = img / KS0, ks = img % KS0, i = ln & 15, q = ln >> 4;
+            const int c = kidx_blk(ks, q);
+            img0[e] = (a.w0_mask0 && c == 0) ? 0.f : W0[(16 * rb + i) * a.w0_ld + c];
         }
     __syncthreads();
 
@@ -929,7 +941,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
     const int64_t per = (n_tiles + total_waves - 1) / total_waves;
     const int64_t w_id = (int64_t)blockIdx.x * NW + wave;
     const int64_t t_begin = min(n_tiles, w_id * per), t_end = min(n_tiles, t_begin + per);
-    const float *act_last = a.act + (int64_t)(NHL - 1) * a.act_layer_stride;
+    const float *act_last = a.act + (RECOMP ? 0 : (int64_t)(NHL - 1) * a.act_layer_stride);
     const bool need_out = a.out_activation == LSE_ACT_SIGMOID;
     const int oc = a.out_cols;
     int cur_row = -1;            // BIAS_ONES: the row whose running sum sits in column 0 of acc0[.][0]
@@ -1015,7 +1027,8 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
             fetch(tile, g, ov, dsg, hv);
         }
         f32x4 hv0[(NHL == 2) ? HB : 1][CT];
-        if constexpr (NHL == 2) {
+        float breg0[RECOMP ? CT : 1][RECOMP ? KS0 : 1];        // RECOMP: layer-0 B operands, requested now, used after dH_last
+        if constexpr (NHL == 2 && !RECOMP) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int cta = ct == 0 ? 0 : act_ct1;
@@ -1023,6 +1036,17 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                 for (int rb = 0; rb < HB; ++rb)
                     hv0[rb][ct] = *reinterpret_cast<const f32x4 *>(act0_t + (unsigned)(((cta * HB + rb) * 64 + lane) * 4));
             }
+        }
+        if constexpr (RECOMP) {
+            const float *in_t = a.in + tile_base * KIN;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int b = 0; b < KIN / 16; ++b) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(in_t + (unsigned)(sl[ct] * KIN + 16 * b + 4 * q));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) breg0[ct][4 * b + r] = v[r];
+                }
         }
         // layer-0 input in B-operand layout for dW0 (lane (j, q), k-step t: in[sample 4t+q][column 16kb+j]), requested now so
         // that its latency hides under the MFMA chain below (single hidden layer; the two-layer kernel has no registers left)
@@ -1084,6 +1108,34 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                 for (int r = 0; r < 4; ++r) dh[rb][ct][r] = hv[rb][ct][r] > 0.f ? dh[rb][ct][r] : 0.f;
         // ---- dH_0 (two hidden layers)
         if constexpr (NHL == 2) {
+            if constexpr (RECOMP) {     // first hidden layer again: relu(W0 * in + row bias), the forward's MFMA chain
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (a.row_bias) {
+                        const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[tile_base + sl[ct]] : tile_base + sl[ct];
+#pragma unroll
+                        for (int rb = 0; rb < HB; ++rb)
+                            hv0[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
+                    } else {
+#pragma unroll
+                        for (int rb = 0; rb < HB; ++rb) hv0[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS0; ++ks)
+#pragma unroll
+                    for (int rb = 0; rb < HB; ++rb) {
+                        const float aw = img0[(rb * KS0 + ks) * 64 + lane];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) hv0[rb][ct] = LSE_MFMA(aw, breg0[ct][ks], hv0[rb][ct]);
+                    }
+#pragma unroll
+                for (int rb = 0; rb < HB; ++rb)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hv0[rb][ct][r] = relu_bits(hv0[rb][ct][r]);
+            }
             wgrad_from_regs<HB, HB, CT>(acc1, tr, dh, hv0, j, q);
             f32x4 d0[HB][CT];
 #pragma unroll
@@ -1364,6 +1416,10 @@ int launch_fwd(const MlpArgs &a, hipStream_t st)
                            lse::option("mlp_act_nt") != 0);
         return lse::check_launch("lse_mlp_fwd");
     }
+    if (a.act && a.act_tiled == 2) {
+        lse::set_error("lse_mlp_fwd: act_tiled = 2 is only understood by the second-generation fused forward");
+        return LSE_E_UNSUPPORTED;
+    }
     switch (cfg) {      // (216 / 116 / 24 were measured and dropped in round 1: DESIGN.md section 4.1)
     case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
     default: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
@@ -1401,17 +1457,17 @@ int launch_bwd_cfg(const MlpArgs &a, hipStream_t st)
     return lse::check_launch("lse_mlp_bwd");
 }
 
-template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES>
+template <int KIN, int WIDTH, int NHL, int INL, bool BIAS_ONES, bool RECOMP = false>
 int launch_bwd2(const MlpArgs &a, hipStream_t st)
 {
     constexpr int HB = WIDTH / 16, NW = 8;
-    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4);
+    constexpr int imgs = HB * 4 + (NHL == 2 ? HB * (WIDTH / 4) : 0) + ((KIN + 15) / 16) * (WIDTH / 4) + (RECOMP ? HB * (KIN / 4) : 0);
     const int64_t tiles = (a.n + 31) / 32;
     const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);     // one resident workgroup per CU
     const size_t lds_bytes = imgs * 256 + (size_t)(NW * kTrWave) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES, RECOMP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
             lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds_bytes, hipGetErrorString(e));
@@ -1419,7 +1475,7 @@ int launch_bwd2(const MlpArgs &a, hipStream_t st)
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
+    hipLaunchKernelGGL((mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES, RECOMP>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
     return lse::check_launch("lse_mlp_bwd");
 }
 
@@ -1429,8 +1485,22 @@ int launch_bwd(const MlpArgs &a, hipStream_t st)
     const int cfg = (int)lse::option("mlp_bwd_cfg");   // CT*10 + NW
     // second-generation kernel: fused weight gradients on tile-major activations, the default tile shape
     if (a.d_params && a.act_tiled && cfg == 28 && !a.d_out_pre && !a.d_act && !a.d_act0 && lse::option("mlp_bwd_impl") == 1) {
+        if constexpr (NHL == 2 && INL == LSE_IN_ROWMAJOR && KIN % 16 == 0) {
+            if (a.act_tiled == 2) {
+                if (a.d_row_bias && a.w0_mask0) return launch_bwd2<KIN, WIDTH, NHL, INL, true, true>(a, st);
+                return launch_bwd2<KIN, WIDTH, NHL, INL, false, true>(a, st);
+            }
+        }
+        if (a.act_tiled == 2) {
+            lse::set_error("lse_mlp_bwd: act_tiled = 2 (first hidden layer recomputed) needs two hidden layers and a row-major input");
+            return LSE_E_UNSUPPORTED;
+        }
         if (a.d_row_bias && a.w0_mask0) return launch_bwd2<KIN, WIDTH, NHL, INL, true>(a, st);
         return launch_bwd2<KIN, WIDTH, NHL, INL, false>(a, st);
+    }
+    if (a.act_tiled == 2) {
+        lse::set_error("lse_mlp_bwd: act_tiled = 2 is only understood by the second-generation fused backward");
+        return LSE_E_UNSUPPORTED;
     }
     switch (cfg) {
     case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
@@ -1525,8 +1595,8 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
 extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act,
                            int32_t act_tiled, const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
                            const uint8_t *selector, float density_scale, float *d_out_pre, float *d_act, float *d_act0,
-                           float *d_in, float *d_params, const int32_t *row_bias_idx, float *d_row_bias, int64_t n,
-                           lse_stream_t stream)
+                           float *d_in, float *d_params, const float *row_bias, const int32_t *row_bias_idx,
+                           float *d_row_bias, int64_t n, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_bwd");
     if (rc) return rc;
@@ -1538,6 +1608,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_bwd: out_cols must be 16 or 4");
     LSE_REQUIRE(!d_sigma || out, "lse_mlp_bwd: the density gradient needs `out`");
     LSE_REQUIRE(!d_row_bias || row_bias_idx, "lse_mlp_bwd: d_row_bias needs row_bias_idx (sorted rows)");
+    LSE_REQUIRE(act_tiled >= 0 && act_tiled <= 2, "lse_mlp_bwd: act_tiled must be 0, 1 or 2");
     LSE_REQUIRE(out_cols == 16 || !d_out_pre, "lse_mlp_bwd: d_out_pre needs the padded 16-column layout");
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
@@ -1546,7 +1617,8 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     a.density_scale = density_scale;
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
-    a.row_bias_idx = row_bias_idx; a.d_row_bias = d_row_bias;
+    a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.d_row_bias = d_row_bias;
+    LSE_REQUIRE(act_tiled != 2 || in, "lse_mlp_bwd: act_tiled = 2 recomputes the first hidden layer and needs `in`");
     fill_view(a, desc);
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);

@@ -385,8 +385,15 @@ class _MlpFn(torch.autograd.Function):
         sigma = torch.empty(n, dtype=torch.float32, device=dev) if density_scale is not None else None
         need_grad = any(t is not None and t.requires_grad for t in (params, x, row_bias))
         tiled = 1 if (FUSED_WGRAD and ACT_TILED) else 0
+        # two hidden layers on a row-major input (the head): the first hidden layer is not saved, the backward recomputes it
+        if tiled and RECOMPUTE_FIRST_LAYER and meta.n_hidden_layers == 2 and meta.in_layout == _lib.LSE_IN_ROWMAJOR \
+                and meta.n_in % 16 == 0 and need_grad and params.requires_grad \
+                and (row_bias is None or not row_bias.requires_grad
+                     or (FUSED_BIAS_GRAD and row_bias_idx is not None and bias_packed_info is not None)):
+            tiled = 2     # (only the second-generation backward recomputes: it needs the bias gradient reduced in-kernel)
         n_act = (n + 15) // 16 * 16 if tiled else n
-        act = torch.empty((meta.n_hidden_layers, n_act, meta.width), dtype=torch.float32, device=dev) if need_grad else None
+        n_saved = meta.n_hidden_layers - (1 if tiled == 2 else 0)
+        act = torch.empty((n_saved, n_act, meta.width), dtype=torch.float32, device=dev) if need_grad else None
         ctx.act_tiled = tiled
         desc = meta.desc()
         _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
@@ -420,8 +427,9 @@ class _MlpFn(torch.autograd.Function):
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
                       ctx.act_tiled, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
-                      _f32(d_params, "d_params", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True) if fused_bias
-                      else None, _f32(d_bias, "d_bias", True), n, _stream())
+                      _f32(d_params, "d_params", True), _f32(row_bias, "row_bias", True),
+                      _chk(row_bias_idx, torch.int32, "row_bias_idx", True) if (fused_bias or ctx.act_tiled == 2) else None,
+                      _f32(d_bias if fused_bias else None, "d_bias", True), n, _stream())
         else:   # reference structure: materialise d_act, then one G^T A reduction per layer (padded outputs only)
             assert out_cols == 16
             d_out_pre = torch.empty((n, 16), dtype=torch.float32, device=dev)
@@ -429,7 +437,7 @@ class _MlpFn(torch.autograd.Function):
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
                       0, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()), None,
-                      _f32(d_in, "d_in", True), None, None, None, n, _stream())
+                      _f32(d_in, "d_in", True), None, None, None, None, n, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
                       ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
                       ctypes.c_void_p(d_params.data_ptr()), n, _stream())
@@ -453,6 +461,7 @@ DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated le
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 FUSED_BIAS_GRAD = True   # per-row bias gradient reduced inside lse_mlp_bwd (False: d_act0 + lse_segment_sum_rows)
+RECOMPUTE_FIRST_LAYER = True   # head MLP: the backward recomputes the first hidden layer instead of reading 1 KiB/sample back
 ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store/load instruction); fused path only
 
 

@@ -462,6 +462,19 @@ def test_mlp_backward_variants_agree(monkeypatch, fused_wgrad, tiled, fused_bias
     _mlp_case(32, 64, 2, 16, None, True, 2051, False, seed=4)
 
 
+@pytest.mark.parametrize("recompute", [True, False])
+def test_mlp_first_hidden_layer_recomputed_or_saved(monkeypatch, recompute):
+    """Two hidden layers on a row-major input (the head): by default the forward does not save the first hidden layer and
+    the backward recomputes it (act_tiled = 2); both routes against the oracle, with and without a per-row bias, ragged N."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "RECOMPUTE_FIRST_LAYER", recompute)
+    for n in (31, 2051):
+        _mlp_case(16, 64, 3, 16, "Sigmoid", False, n, True, seed=5)
+        _mlp_case(16, 64, 3, 16, None, False, n, False, seed=6)
+    _mlp_case(64, 64, 3, 16, "Sigmoid", False, 1000, True, seed=7)      # nerfstudio-style 64-wide head input
+    _mlp_case(16, 32, 3, 16, None, False, 777, True, seed=8)
+
+
 def test_mlp_row_bias_grad_many_short_rows():
     """Rows of 0..3 samples: several row boundaries inside every 16-sample tile of the fused bias-gradient scan."""
     ops = _ops()
