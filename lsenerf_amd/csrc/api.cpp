@@ -23,7 +23,7 @@ static Option g_options[] = {
     {"mlp_fwd_cfg", {28}},
     {"mlp_bwd_cfg", {28}},
     {"mlp_bwd_impl", {1}},
-    {"mlp_fwd_impl", {1}},
+    {"mlp_fwd_impl", {2}},
     {"mlp_act_nt", {0}},
     {"traverse_vec", {1}},
 };

@@ -1252,6 +1252,8 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
     flush_wgrad<1, HB>(a.d_params + a.rest_off + NP1, WIDTH, WIDTH, accO, j, q);
 }
 
+#include "mlp_x6.h"
+
 // ------------------------------------------------------------------------------------------------------
 // weight gradients:  dW[M x K] += G[N x M]^T * A[N x K]   (samples are the MFMA k dimension, so both
 // operands are read straight from their row-major rows: lane (i, q) of k-step s reads row 4s+q, column i)
@@ -1407,7 +1409,18 @@ template <int KIN, int WIDTH, int NHL, int INL>
 int launch_fwd(const MlpArgs &a, hipStream_t st)
 {
     const int cfg = (int)lse::option("mlp_fwd_cfg");   // CT*10 + NW
-    if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") == 1) {
+    if constexpr (WIDTH == 64 && ((KIN == 16 && INL == LSE_IN_ROWMAJOR) || KIN == 32)) {
+        // third generation: f32-equivalent arithmetic on the bf16 matrix cores (mlp_x6.h)
+        if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") == 2) {
+            const int64_t tiles3 = (a.n + 31) / 32;
+            const int blocks3 = (int)std::min<int64_t>((tiles3 + 7) / 8, 512);
+            constexpr int lds3 = X6Fwd<KIN, NHL, INL>::lds_bytes;
+            hipLaunchKernelGGL((mlp_fwd3_kernel<KIN, NHL, INL>), dim3(blocks3), dim3(512), lds3, st, a,
+                               lse::option("mlp_act_nt") != 0);
+            return lse::check_launch("lse_mlp_fwd");
+        }
+    }
+    if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") >= 1) {
         constexpr int HB2 = WIDTH / 16;
         constexpr int imgs2 = HB2 * (KIN / 4) + (NHL == 2 ? HB2 * (WIDTH / 4) : 0) + WIDTH / 4;
         const int64_t tiles2 = (a.n + 31) / 32;
@@ -1479,10 +1492,42 @@ int launch_bwd2(const MlpArgs &a, hipStream_t st)
     return lse::check_launch("lse_mlp_bwd");
 }
 
+template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES>
+int launch_bwd3(const MlpArgs &a, hipStream_t st)
+{
+    constexpr int lds_bytes = X6Bwd<KIN, NHL>::lds_bytes;
+    const int64_t tiles = (a.n + 31) / 32;
+    const int blocks = (int)std::min<int64_t>((tiles + 7) / 8, 256);     // one resident workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) {
+            lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
+            return LSE_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES>), dim3(blocks), dim3(512), lds_bytes, st, a);
+    return lse::check_launch("lse_mlp_bwd");
+}
+
 template <int KIN, int WIDTH, int NHL, int INL>
 int launch_bwd(const MlpArgs &a, hipStream_t st)
 {
     const int cfg = (int)lse::option("mlp_bwd_cfg");   // CT*10 + NW
+    if (a.act_tiled == 3) {     // nothing saved: third generation, hidden layers recomputed on the bf16 matrix cores (mlp_x6.h)
+        if constexpr (WIDTH == 64 && ((KIN == 16 && NHL == 2 && INL == LSE_IN_ROWMAJOR) || (KIN == 32 && NHL == 1))) {
+            if (a.d_params && !a.d_out_pre && !a.d_act && !a.d_act0) {
+                if (a.row_bias && a.d_row_bias && a.w0_mask0) return launch_bwd3<KIN, NHL, INL, true, true>(a, st);
+                if (a.row_bias) return launch_bwd3<KIN, NHL, INL, true, false>(a, st);
+                return launch_bwd3<KIN, NHL, INL, false, false>(a, st);
+            }
+        }
+        lse::set_error("lse_mlp_bwd: act_tiled = 3 (all hidden layers recomputed) is built for the 16->64->64 row-major and "
+                       "32->64 shapes with fused weight gradients and no materialised activation gradients");
+        return LSE_E_UNSUPPORTED;
+    }
     // second-generation kernel: fused weight gradients on tile-major activations, the default tile shape
     if (a.d_params && a.act_tiled && cfg == 28 && !a.d_out_pre && !a.d_act && !a.d_act0 && lse::option("mlp_bwd_impl") == 1) {
         if constexpr (NHL == 2 && INL == LSE_IN_ROWMAJOR && KIN % 16 == 0) {
@@ -1602,13 +1647,13 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     if (rc) return rc;
     LSE_REQUIRE(n >= 0, "lse_mlp_bwd: n < 0");
     if (n == 0) return LSE_OK;
-    LSE_REQUIRE(params && act && d_out, "lse_mlp_bwd: null pointer");
+    LSE_REQUIRE(params && d_out && (act || act_tiled == 3), "lse_mlp_bwd: null pointer");
     LSE_REQUIRE(desc->out_activation == LSE_ACT_NONE || out, "lse_mlp_bwd: sigmoid backward needs `out`");
     LSE_REQUIRE(!d_params || in, "lse_mlp_bwd: fused weight gradients need the layer-0 input `in`");
     LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_bwd: out_cols must be 16 or 4");
     LSE_REQUIRE(!d_sigma || out, "lse_mlp_bwd: the density gradient needs `out`");
     LSE_REQUIRE(!d_row_bias || row_bias_idx, "lse_mlp_bwd: d_row_bias needs row_bias_idx (sorted rows)");
-    LSE_REQUIRE(act_tiled >= 0 && act_tiled <= 2, "lse_mlp_bwd: act_tiled must be 0, 1 or 2");
+    LSE_REQUIRE(act_tiled >= 0 && act_tiled <= 3, "lse_mlp_bwd: act_tiled must be 0, 1, 2 or 3");
     LSE_REQUIRE(out_cols == 16 || !d_out_pre, "lse_mlp_bwd: d_out_pre needs the padded 16-column layout");
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
@@ -1618,7 +1663,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
     a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.d_row_bias = d_row_bias;
-    LSE_REQUIRE(act_tiled != 2 || in, "lse_mlp_bwd: act_tiled = 2 recomputes the first hidden layer and needs `in`");
+    LSE_REQUIRE(act_tiled < 2 || in, "lse_mlp_bwd: act_tiled = 2 / 3 recompute hidden layers and need `in`");
     fill_view(a, desc);
     hipStream_t st = lse::as_stream(stream);
     LSE_MLP_DISPATCH(launch_bwd, desc, a, st);

@@ -391,9 +391,16 @@ class _MlpFn(torch.autograd.Function):
                 and (row_bias is None or not row_bias.requires_grad
                      or (FUSED_BIAS_GRAD and row_bias_idx is not None and bias_packed_info is not None)):
             tiled = 2     # (only the second-generation backward recomputes: it needs the bias gradient reduced in-kernel)
+        # third generation (mlp_x6.h): nothing is saved, the backward recomputes every hidden layer on the bf16 matrix cores
+        if tiled and RECOMPUTE_ALL and meta.width == 64 and need_grad and params.requires_grad \
+                and ((meta.n_in == 16 and meta.n_hidden_layers == 2 and meta.in_layout == _lib.LSE_IN_ROWMAJOR)
+                     or (meta.n_in == 32 and meta.n_hidden_layers == 1)) \
+                and (row_bias is None or not row_bias.requires_grad
+                     or (FUSED_BIAS_GRAD and row_bias_idx is not None and bias_packed_info is not None)):
+            tiled = 3
         n_act = (n + 15) // 16 * 16 if tiled else n
         n_saved = meta.n_hidden_layers - (1 if tiled == 2 else 0)
-        act = torch.empty((n_saved, n_act, meta.width), dtype=torch.float32, device=dev) if need_grad else None
+        act = torch.empty((n_saved, n_act, meta.width), dtype=torch.float32, device=dev) if (need_grad and tiled != 3) else None
         ctx.act_tiled = tiled
         desc = meta.desc()
         _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
@@ -424,11 +431,12 @@ class _MlpFn(torch.autograd.Function):
         scale = float(ctx.density_scale or 0.0)
         sel = _chk(selector, torch.uint8, "selector", True)
         if ctx.act_tiled or FUSED_WGRAD or d_params is None:
-            _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
+            _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
+                      _f32(act, "act", ctx.act_tiled == 3),
                       ctx.act_tiled, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
                       _f32(d_params, "d_params", True), _f32(row_bias, "row_bias", True),
-                      _chk(row_bias_idx, torch.int32, "row_bias_idx", True) if (fused_bias or ctx.act_tiled == 2) else None,
+                      _chk(row_bias_idx, torch.int32, "row_bias_idx", True) if (fused_bias or ctx.act_tiled >= 2) else None,
                       _f32(d_bias if fused_bias else None, "d_bias", True), n, _stream())
         else:   # reference structure: materialise d_act, then one G^T A reduction per layer (padded outputs only)
             assert out_cols == 16
@@ -461,6 +469,7 @@ DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated le
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)
 FUSED_BIAS_GRAD = True   # per-row bias gradient reduced inside lse_mlp_bwd (False: d_act0 + lse_segment_sum_rows)
+RECOMPUTE_ALL = True   # head + base MLPs: save no activations at all, third-generation backward (bf16 pieces) recomputes them
 RECOMPUTE_FIRST_LAYER = True   # head MLP: the backward recomputes the first hidden layer instead of reading 1 KiB/sample back
 ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store/load instruction); fused path only
 

@@ -475,6 +475,26 @@ def test_mlp_first_hidden_layer_recomputed_or_saved(monkeypatch, recompute):
     _mlp_case(16, 32, 3, 16, None, False, 777, True, seed=8)
 
 
+@pytest.mark.parametrize("recompute_all,fwd_impl", [(True, 2), (True, 1), (False, 2)])
+def test_mlp_third_generation_bf16_pieces(monkeypatch, recompute_all, fwd_impl):
+    """lsenerf_amd/csrc/mlp_x6.h: f32 operands cut into three bf16 pieces, six piece products per multiply on the bf16 matrix
+    cores (f32-equivalent error bound -> the SAME tolerances as the f32-MFMA kernels), forward (mlp_fwd_impl = 2) and the
+    backward that recomputes every hidden layer (act_tiled = 3), head and base shapes, ragged sizes, rows of every length."""
+    from lsenerf_amd import _lib
+    ops = _ops()
+    monkeypatch.setattr(ops, "RECOMPUTE_ALL", recompute_all)
+    old = _lib.get_option("mlp_fwd_impl")
+    _lib.set_option("mlp_fwd_impl", fwd_impl)
+    try:
+        for n in (1, 17, 31, 32, 33, 2051, 9000):
+            _mlp_case(16, 64, 3, 16, "Sigmoid", False, n, True, seed=20 + n)
+            _mlp_case(16, 64, 3, 16, None, False, n, False, seed=21 + n)
+            _mlp_case(32, 64, 2, 16, None, True, n, False, seed=22 + n)
+        _mlp_case(32, 64, 2, 16, None, False, 1500, False, seed=23)      # row-major 32-wide input
+    finally:
+        _lib.set_option("mlp_fwd_impl", old)
+
+
 def test_mlp_row_bias_grad_many_short_rows():
     """Rows of 0..3 samples: several row boundaries inside every 16-sample tile of the fused bias-gradient scan."""
     ops = _ops()
