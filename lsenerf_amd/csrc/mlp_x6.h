@@ -317,7 +317,7 @@ struct X6Fwd {
     static constexpr int IMG0 = 3 * HB * 64;                       // u32x4 entries
     static constexpr int IMGH = (NHL == 2) ? 3 * HB * S * 64 : 0;
     static constexpr int IMGO = 3 * 1 * S * 64;
-    static constexpr int lds_bytes = (IMG0 + IMGH + IMGO) * 16;
+    static constexpr int lds_bytes = (IMG0 + IMGH + IMGO + 128) * 16;      // + the two "minus identity" operands
 };
 
 template <int KIN, int INL, int CT>
@@ -349,14 +349,14 @@ __device__ __forceinline__ void load_in_x6(const MlpArgs &a, int64_t tile, int j
 
 // first hidden layer of one tile: h = relu(W0 * in + bias), shared by the forward and the recomputing backward so that both
 // produce the same bits
-template <int KIN, int CT>
+template <int KIN, int CT, typename NI>
 __device__ __forceinline__ void first_layer_x6(f32x4 (&h)[4][CT], const u32x4 *img0, const f32x4 (&raw)[CT][KIN / 16],
-                                               const u32x4 (&nI)[2], int lane)
+                                               const NI &nI, int lane)
 {
     if constexpr (KIN == 16) {
         PiecesB16 x[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) split_in16<false>(raw[ct][0], nI, x[ct]);
+        for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, x[ct]);
         layer16_x6_ct<4, CT>(h, img0, x, lane);
     } else {
         PiecesB<2> x[CT];
@@ -371,7 +371,6 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 {
     using C = X6Fwd<KIN, NHL, INL>;
     constexpr int CT = 2, NW = 8, TS = 16 * CT, HB = 4, WIDTH = 64;
-    constexpr bool MS = (KIN == 32);      // pieces cut on the matrix core (base shape) / on the vector ALU (head shape: see DESIGN.md)
     static_assert(KIN == 16 || KIN == 32, "first layer: 16 or 32 inputs");
     extern __shared__ float lds[];
     u32x4 *img0 = reinterpret_cast<u32x4 *>(lds), *imgH = img0 + C::IMG0, *imgO = imgH + C::IMGH;
@@ -383,6 +382,12 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
     else stage_in32_image<HB>(img0, W0, a.w0_ld, a.w0_mask0, 64 * NW);
     if constexpr (NHL == 2) stage_chain_image<HB, 2>(imgH, W1, WIDTH, WIDTH, 64 * NW);
     stage_chain_image<1, 2>(imgO, Wo, WIDTH, 16, 64 * NW);
+    if (threadIdx.x < 64) {
+        u32x4 t[2];
+        neg_identity(threadIdx.x, t);
+        imgO[C::IMGO + threadIdx.x] = t[0];
+        imgO[C::IMGO + 64 + threadIdx.x] = t[1];
+    }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -394,8 +399,11 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
     const int64_t w_id = (int64_t)blockIdx.x * NW + wave;
     const int64_t t_begin = min(n_tiles, w_id * per), t_end = min(n_tiles, t_begin + per);
     const int oc = a.out_cols;
-    u32x4 nI[2];
-    neg_identity(lane, nI);
+    struct NegI {          // "minus identity" operands from LDS (8 registers less: one more wave per SIMD for the base shape)
+        const u32x4 *p;
+        __device__ __forceinline__ u32x4 operator[](int b) const { return p[64 * b]; }
+    };
+    const NegI nI{imgO + C::IMGO + lane};
 
     f32x4 raw_nx[CT][KIN / 16];
     if (t_begin < t_end) load_in_x6<KIN, INL, CT>(a, t_begin, j, q, raw_nx);
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) split_pair<MS>(h[2 * s2][ct], h[2 * s2 + 1][ct], nI, x[ct].p[s2]);
+            for (int s2 = 0; s2 < 2; ++s2) split_pair<true>(h[2 * s2][ct], h[2 * s2 + 1][ct], nI, x[ct].p[s2]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hidden layer
         if constexpr (NHL == 2) {
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) split_pair<MS>(h2[2 * s2][ct], h2[2 * s2 + 1][ct], nI, x[ct].p[s2]);
+                for (int s2 = 0; s2 < 2; ++s2) split_pair<true>(h2[2 * s2][ct], h2[2 * s2 + 1][ct], nI, x[ct].p[s2]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- output layer
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
 {
     using C = X6Bwd<KIN, NHL>;
     constexpr int CT = 2, NW = 8, TS = 16 * CT, HB = 4, WIDTH = 64, S0 = C::S0, KB0 = KIN / 16;
-    constexpr bool MS = (KIN == 32);      // pieces cut on the matrix core (base) / on the vector ALU (head: registers)
+    constexpr bool MS = (KIN == 32);      // remainder MFMAs on pairs of row blocks (base) / on single blocks (head: fewer live registers)
     static_assert((KIN == 16 && NHL == 2 && INL == LSE_IN_ROWMAJOR) || (KIN == 32 && NHL == 1), "head or base shape");
     extern __shared__ float lds[];
     uint8_t *imgW0 = reinterpret_cast<uint8_t *>(lds);
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
     // f32x4 (4 consecutive columns of one sample) -> plain pieces
     auto split4 = [&](const f32x4 v, Halves &h) {
         uint32_t hi[2], mid[2], lo[2];
-        split_half<MS>(v, nI, hi, mid, lo);
+        split_half<true>(v, nI, hi, mid, lo);
         h.p[0] = (u32x2){hi[0], hi[1]};
         h.p[1] = (u32x2){mid[0], mid[1]};
         h.p[2] = (u32x2){lo[0], lo[1]};
@@ -760,19 +768,21 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
             for (int ct = 0; ct < CT; ++ct) split_pair<true>(c0[ct], c1[ct], nI, x[ct].p[s2]);
         }
     };
-    // vector-ALU route: one block at a time, as soon as it is complete (fewer live registers)
+    // head shape (registers are scarce): one block at a time, as soon as it is complete -- the same two remainder MFMAs per
+    // block as the paired form (the unused half of the B operand is zero)
     auto split_block_valu = [&](int s2, int b, const f32x4 (&c)[CT], PiecesB<HB> (&x)[CT]) {
         if constexpr (!MS) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {
+                uint32_t hi[2], mid[2], lo[2];
+                split_half<true>(c[ct], nI, hi, mid, lo);
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
-                    uint32_t hi, mid, lo;
-                    split2(c[ct][2 * w2], c[ct][2 * w2 + 1], hi, mid, lo);
-                    x[ct].p[s2][0][2 * b + w2] = hi;
-                    x[ct].p[s2][1][2 * b + w2] = mid;
-                    x[ct].p[s2][2][2 * b + w2] = lo;
+                    x[ct].p[s2][0][2 * b + w2] = hi[w2];
+                    x[ct].p[s2][1][2 * b + w2] = mid[w2];
+                    x[ct].p[s2][2][2 * b + w2] = lo[w2];
                 }
+            }
         }
     };
     auto write_buf_rb = [&](int rb, const PiecesB<HB> (&x)[CT]) {
@@ -808,17 +818,14 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
         // ---- loads
         f32x4 raw[CT][KIN / 16];
         load_in_x6<KIN, INL, CT>(a, tile, j, q, raw);
-        // per-row bias: row of this lane's sample per column tile (accumulator layout) and of samples 16ct + 4q + r (operand
-        // layout of H0^T), as 32-bit offsets from a wave-uniform base
+        // per-row bias: row of this lane's sample per column tile (accumulator layout), as a 32-bit offset from a wave-uniform base
         const float *rbase = a.row_bias;
         int brow[CT] = {0, 0};
         if constexpr (BIAS) {
             if (a.row_bias_idx) {
                 const int32_t *idx_t = a.row_bias_idx + tile_base;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    brow[ct] = idx_t[sl[ct]];
-                }
+                for (int ct = 0; ct < CT; ++ct) brow[ct] = idx_t[sl[ct]];
             } else {
                 rbase = a.row_bias + tile_base * WIDTH;
 #pragma unroll
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
             u32x4 xin[CT][3];
             if constexpr (KIN == 16) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) split_in16<MS>(raw[ct][0], nI, xin16[ct]);
+                for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
             } else {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) split_pair<MS>(raw[ct][0], raw[ct][1], nI, xin[ct]);
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
             {
                 PiecesB16 xin16[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) split_in16<MS>(raw[ct][0], nI, xin16[ct]);
+                for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
                 int trow[CT][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // bias rows of samples 16ct + 4q + r
                 if constexpr (BIAS) {
                     if (a.row_bias_idx) {
@@ -1048,7 +1055,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
                         for (int r = 0; r < 4; ++r) t0[ct][r] = relu_bits(t0[ct][r]);
                     }
                     u32x4 hb[3];
-                    split_pair<MS>(t0[0], t0[1], nI, hb);
+                    split_pair<true>(t0[0], t0[1], nI, hb);
 #pragma unroll
                     for (int mb = 0; mb < HB; ++mb) {
                         u32x4 ga[3];
