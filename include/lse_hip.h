@@ -189,21 +189,30 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
  *   "hash_fwd_mapping"  workgroup -> (level, chunk) order of lse_hash_fwd: 4 = level-major, finest level first (default),
  *                       3 = level-major coarse first, 0 / 1 = XCD-bound levels, 2 = level-interleaved
  *   "mlp_fwd_cfg" / "mlp_bwd_cfg"  CT * 10 + NW tile shape of the fused MLP kernels (default 28)
- *   "mlp_fwd_impl"      1 = second-generation fused forward (contiguous tiles per wave, 4 waves per SIMD; default), 0 = first
+ *   "mlp_fwd_impl"      2 = third-generation fused forward where it is built (width 64, 16 row-major or 32 inputs; default):
+ *                       f32 operands cut into three bf16 pieces, six piece products per multiply on the bf16 matrix cores,
+ *                       f32 accumulate -- the f32 error bound (csrc/mlp_x6.h); 1 = f32-MFMA forward (second generation:
+ *                       contiguous tiles per wave, 4 waves per SIMD), 0 = first generation.  The values of the two
+ *                       arithmetic routes differ in the last bits (both within f32 rounding of the exact result)
  *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
  *                       MFMAs; default), 0 = first-generation kernel
  *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
- * Returns LSE_E_INVALID for an unknown name.  Results never depend on these (speed only). */
+ * Returns LSE_E_INVALID for an unknown name.  Integer outputs never depend on these; floating-point results agree within
+ * rounding (mlp_fwd_impl chooses between two arithmetic routes of the same accuracy, the rest only reorder launches). */
 int lse_set_option(const char *name, int64_t value);
 int lse_get_option(const char *name, int64_t *value);
 
-/* fused MLP forward on f32 MFMA.  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
+/* fused MLP forward on the matrix cores (f32 MFMA, or bf16 MFMA on three-piece operands with the same error bound: option
+ * "mlp_fwd_impl").  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
  * [n_hidden_layers][N][width] (what lse_mlp_wgrad reads); act_tiled = 1 -> tile-major, an opaque workspace of
  * n_hidden_layers * roundup(N,16) * width floats that only lse_mlp_bwd (same act_tiled) understands; act_tiled = 2 (two
  * hidden layers, row-major input): tile-major WITHOUT the first hidden layer ((n_hidden_layers - 1) * roundup(N,16) * width
  * floats) -- lse_mlp_bwd recomputes it from `in` and `row_bias` (32 extra MFMAs per 32 samples against 2 KiB per sample of
- * activation traffic), bit-identical to what the forward computed.
+ * activation traffic), bit-identical to what the forward computed;  act_tiled = 3 (width 64 with 16 row-major inputs and two
+ * hidden layers, or 32 inputs and one): NOTHING is saved (act may be NULL) -- lse_mlp_bwd recomputes every hidden layer on the
+ * bf16 matrix cores (three-piece operands, csrc/mlp_x6.h), fused weight gradients only (d_params required; d_out_pre / d_act /
+ * d_act0 not available).
  * out is [N,16] (out_cols = 16) or the compact [N,4] holding outputs 0..3 (out_cols = 4, e.g. rgb).
  * sigma_out (nullable): fused density head sigma[N] = density_scale * exp(out[:,0]) * selector (trunc_exp,
  * R:lse_nerf/lse_field.py:286-287); selector nullable. */

@@ -24,6 +24,7 @@ static Option g_options[] = {
     {"mlp_bwd_cfg", {28}},
     {"mlp_bwd_impl", {1}},
     {"mlp_fwd_impl", {2}},
+    {"mlp_bwd3_cfg", {208}},
     {"mlp_act_nt", {0}},
     {"traverse_vec", {1}},
 };

@@ -1492,15 +1492,16 @@ int launch_bwd2(const MlpArgs &a, hipStream_t st)
     return lse::check_launch("lse_mlp_bwd");
 }
 
-template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES>
-int launch_bwd3(const MlpArgs &a, hipStream_t st)
+template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES, int CT, int NW>
+int launch_bwd3_cfg(const MlpArgs &a, hipStream_t st)
 {
-    constexpr int lds_bytes = X6Bwd<KIN, NHL>::lds_bytes;
-    const int64_t tiles = (a.n + 31) / 32;
-    const int blocks = (int)std::min<int64_t>((tiles + 7) / 8, 256);     // one resident workgroup per CU
+    constexpr int lds_bytes = X6Bwd<KIN, NHL, CT, NW>::lds_bytes;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
+    const int64_t tiles = (a.n + 16 * CT - 1) / (16 * CT);
+    const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);     // one resident workgroup per CU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES, CT, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
@@ -1508,8 +1509,18 @@ int launch_bwd3(const MlpArgs &a, hipStream_t st)
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES>), dim3(blocks), dim3(512), lds_bytes, st, a);
+    hipLaunchKernelGGL((mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES, CT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
     return lse::check_launch("lse_mlp_bwd");
+}
+
+template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES>
+int launch_bwd3(const MlpArgs &a, hipStream_t st)
+{
+    switch ((int)lse::option("mlp_bwd3_cfg")) {      // CT * 100 + NW
+    case 112: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 12>(a, st);
+    case 108: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 8>(a, st);
+    default: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 8>(a, st);
+    }
 }
 
 template <int KIN, int WIDTH, int NHL, int INL>

@@ -590,22 +590,26 @@ __device__ __forceinline__ void combos16_lds(F rd, u32x4 (&c)[3])
     c[2] = (u32x4){h1[0], h1[1], m1[0], m1[1]};
 }
 
-template <int KIN, int NHL>
+template <int KIN, int NHL, int CT, int NW>
 struct X6Bwd {
     static constexpr int S0 = KIN / 16;
     static constexpr int W0_PIECE = 64 * 32 * S0, W1_PIECE = (NHL == 2) ? 64 * 128 : 0, WO_PIECE = 16 * 128;
     static constexpr int W_BYTES = 3 * (W0_PIECE + W1_PIECE + WO_PIECE);
-    static constexpr int BUF_PIECE = 32 * 128, SM_PIECE = 32 * 32;
+    static constexpr int BUF_PIECE = 16 * CT * 128, SM_PIECE = 16 * CT * 32;
     static constexpr int WAVE_BYTES = 3 * (BUF_PIECE + SM_PIECE);
     static constexpr int NI_BYTES = 2 * 1024;                 // the two "minus identity" A operands, one 16-byte entry per lane
-    static constexpr int lds_bytes = W_BYTES + NI_BYTES + 8 * WAVE_BYTES;
+    static constexpr int lds_bytes = W_BYTES + NI_BYTES + NW * WAVE_BYTES;
 };
 
-template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES>
-__global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
+// CT = column tiles (16 samples) per wave tile, NW = waves per workgroup (one workgroup per CU).  CT = 2 / NW = 8: the weight
+// operands are read once per 32 samples, two waves per SIMD.  CT = 1: half the per-tile state (registers, LDS tile) so that more
+// waves fit a SIMD; the weight gradients then sum over 16 samples per product and use the k = 16 form (three MFMAs on two-piece
+// windows) -- the same matrix-core cycles per sample.
+template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES, int CT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
 {
-    using C = X6Bwd<KIN, NHL>;
-    constexpr int CT = 2, NW = 8, TS = 16 * CT, HB = 4, WIDTH = 64, S0 = C::S0, KB0 = KIN / 16;
+    using C = X6Bwd<KIN, NHL, CT, NW>;
+    constexpr int TS = 16 * CT, HB = 4, WIDTH = 64, S0 = C::S0, KB0 = KIN / 16;
     constexpr bool MS = (KIN == 32);      // remainder MFMAs on pairs of row blocks (base) / on single blocks (head: fewer live registers)
     static_assert((KIN == 16 && NHL == 2 && INL == LSE_IN_ROWMAJOR) || (KIN == 32 && NHL == 1), "head or base shape");
     extern __shared__ float lds[];
@@ -695,21 +699,54 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // the three pieces of a 16-neuron block of the [32 x 64] tile as an MFMA operand (lane = neuron, slots = samples 4q+t | 16+4q+t)
-    auto tr_block = [&](int nb, u32x4 (&o)[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const u32x2 lo = lds_tr_read(buf + (p * C::BUF_PIECE + so_t[nb]));
-            const u32x2 hi = lds_tr_read(buf + (p * C::BUF_PIECE + 2048 + so_t[nb]));
-            o[p] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    // Operands of the weight-gradient products (k = samples), read transposed from the tile (lane = neuron).
+    //   CT = 2: the three pieces, slots = samples 4q+t | 16+4q+t  -> six piece products (mfma6)
+    //   CT = 1: k = 16 windows of two pieces (slots 0..3 | 4..7 carry the same samples 4q+t):
+    //           A side (hi|hi), (mid|lo), (hi|mid);  B side (hi|mid), (hi|hi), (lo|mid)  -> three products
+    auto windows = [&](auto rd, bool a_side, u32x4 (&o)[3]) {     // rd(piece) -> the 4 slots of that piece (2 registers)
+        if (a_side) {
+            const u32x2 h = rd(0), m = rd(1), l = rd(2);
+            o[0] = (u32x4){h[0], h[1], h[0], h[1]};
+            o[1] = (u32x4){m[0], m[1], l[0], l[1]};
+            o[2] = (u32x4){h[0], h[1], m[0], m[1]};
+        } else {
+            const u32x2 h = rd(0), m = rd(1), l = rd(2);
+            o[0] = (u32x4){h[0], h[1], m[0], m[1]};
+            o[1] = (u32x4){h[0], h[1], h[0], h[1]};
+            o[2] = (u32x4){l[0], l[1], m[0], m[1]};
         }
     };
-    auto tr_small = [&](u32x4 (&o)[3]) {
+    auto tr_block = [&](int nb, bool a_side, u32x4 (&o)[3]) {
+        if constexpr (CT == 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const u32x2 lo = lds_tr_read(sm + (p * C::SM_PIECE + sm_t));
-            const u32x2 hi = lds_tr_read(sm + (p * C::SM_PIECE + 512 + sm_t));
-            o[p] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            for (int p = 0; p < 3; ++p) {
+                const u32x2 lo = lds_tr_read(buf + (p * C::BUF_PIECE + so_t[nb]));
+                const u32x2 hi = lds_tr_read(buf + (p * C::BUF_PIECE + 2048 + so_t[nb]));
+                o[p] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+        } else {
+            windows([&](int p) { return lds_tr_read(buf + (p * C::BUF_PIECE + so_t[nb])); }, a_side, o);
+        }
+    };
+    auto tr_small = [&](bool a_side, u32x4 (&o)[3]) {
+        if constexpr (CT == 2) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const u32x2 lo = lds_tr_read(sm + (p * C::SM_PIECE + sm_t));
+                const u32x2 hi = lds_tr_read(sm + (p * C::SM_PIECE + 512 + sm_t));
+                o[p] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+        } else {
+            windows([&](int p) { return lds_tr_read(sm + (p * C::SM_PIECE + sm_t)); }, a_side, o);
+        }
+    };
+    auto wg_mfma = [&](const u32x4 (&a3)[3], const u32x4 (&b3)[3], f32x4 c) {
+        if constexpr (CT == 2) {
+            return mfma6(a3, b3, c);
+        } else {
+            c = LSE_MFMA_BF(a3[2], b3[2], c);
+            c = LSE_MFMA_BF(a3[1], b3[1], c);
+            return LSE_MFMA_BF(a3[0], b3[0], c);
         }
     };
     // write the pieces of one column tile (accumulator layout, 4 row blocks) into the [32 x 64] tile
@@ -820,7 +857,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
         load_in_x6<KIN, INL, CT>(a, tile, j, q, raw);
         // per-row bias: row of this lane's sample per column tile (accumulator layout), as a 32-bit offset from a wave-uniform base
         const float *rbase = a.row_bias;
-        int brow[CT] = {0, 0};
+        int brow[CT] = {};
         if constexpr (BIAS) {
             if (a.row_bias_idx) {
                 const int32_t *idx_t = a.row_bias_idx + tile_base;
@@ -863,7 +900,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
         }
         // ---- first hidden layer again, one row block at a time: relu(W0 in + bias) -> mask bits + pieces
         PiecesB<HB> x[CT];
-        uint32_t m0[CT] = {0u, 0u}, m1[CT] = {0u, 0u};      // ReLU masks, bit 4rb + r
+        uint32_t m0[CT] = {}, m1[CT] = {};      // ReLU masks, bit 4rb + r
         {
             PiecesB16 xin16[CT];
             u32x4 xin[CT][3];
@@ -972,12 +1009,12 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
         lds_sync();
         {
             u32x4 ga[3];
-            tr_small(ga);
+            tr_small(true, ga);
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
                 u32x4 hb[3];
-                tr_block(kb, hb);
-                accO[0][kb] = mfma6(ga, hb, accO[0][kb]);
+                tr_block(kb, false, hb);
+                accO[0][kb] = wg_mfma(ga, hb, accO[0][kb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1022,7 +1059,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
                 PiecesB16 xin16[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
-                int trow[CT][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // bias rows of samples 16ct + 4q + r
+                int trow[CT][4] = {};      // bias rows of samples 16ct + 4q + r
                 if constexpr (BIAS) {
                     if (a.row_bias_idx) {
                         const int32_t *idx_t = a.row_bias_idx + tile_base;
@@ -1055,12 +1092,20 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
                         for (int r = 0; r < 4; ++r) t0[ct][r] = relu_bits(t0[ct][r]);
                     }
                     u32x4 hb[3];
-                    split_pair<true>(t0[0], t0[1], nI, hb);
+                    if constexpr (CT == 2) {
+                        split_pair<true>(t0[0], t0[CT - 1], nI, hb);
+                    } else {
+                        uint32_t hi[2], mid[2], lo[2];
+                        split_half<true>(t0[0], nI, hi, mid, lo);
+                        hb[0] = (u32x4){hi[0], hi[1], mid[0], mid[1]};
+                        hb[1] = (u32x4){hi[0], hi[1], hi[0], hi[1]};
+                        hb[2] = (u32x4){lo[0], lo[1], mid[0], mid[1]};
+                    }
 #pragma unroll
                     for (int mb = 0; mb < HB; ++mb) {
                         u32x4 ga[3];
-                        tr_block(mb, ga);
-                        acc1[mb][nb] = mfma6(ga, hb, acc1[mb][nb]);
+                        tr_block(mb, true, ga);
+                        acc1[mb][nb] = wg_mfma(ga, hb, acc1[mb][nb]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1105,7 +1150,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
             read_buf_own(x);         // dH0 pieces (B operand of dIn)
         }
         // ---- per-row bias gradient of a column tile that straddles two rows (rare): segmented scan on dH0 = hi + mid + lo
-        float ones[CT] = {0.f, 0.f};
+        float ones[CT] = {};
         if (BIAS && a.d_row_bias) {
             bool col_taken = false;          // both column tiles feed ONE product: only one row per tile may use the column
 #pragma unroll
@@ -1151,38 +1196,52 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd3_kernel(MlpArgs a)
                 write_sm(ct, h);
             }
             lds_sync();
-            tr_small(ib[0]);
+            tr_small(false, ib[0]);
             if constexpr (BIAS_ONES) {
                 // the unweighted input column 0 carries the constant 1 of the samples whose column tile belongs to one row
-                const uint32_t o0 = ones[0] != 0.f ? 0x3F803F80u : 0u, o1 = ones[1] != 0.f ? 0x3F803F80u : 0u;
+                const uint32_t o0 = ones[0] != 0.f ? 0x3F803F80u : 0u, o1 = ones[CT - 1] != 0.f ? 0x3F803F80u : 0u;
                 if (j == 0) {
-                    ib[0][0] = (u32x4){o0, o0, o1, o1};
-                    ib[0][1] = (u32x4){0u, 0u, 0u, 0u};
-                    ib[0][2] = (u32x4){0u, 0u, 0u, 0u};
+                    if constexpr (CT == 2) {
+                        ib[0][0] = (u32x4){o0, o0, o1, o1};
+                        ib[0][1] = (u32x4){0u, 0u, 0u, 0u};
+                        ib[0][2] = (u32x4){0u, 0u, 0u, 0u};
+                    } else {            // windows (hi|mid), (hi|hi), (lo|mid) of the constant: hi = 1, mid = lo = 0
+                        ib[0][0] = (u32x4){o0, o0, 0u, 0u};
+                        ib[0][1] = (u32x4){o0, o0, o0, o0};
+                        ib[0][2] = (u32x4){0u, 0u, 0u, 0u};
+                    }
                 }
             }
         } else {
             lds_sync();
 #pragma unroll
             for (int nb = 0; nb < KB0; ++nb) {
-                float v[8];
+                float v[4 * CT];
                 const int col = 16 * nb + j;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < 4 * CT; ++t) {
                     int s_t = 16 * (t >> 2) + 4 * q + (t & 3);
                     s_t = s_t < n_rem ? s_t : n_rem - 1;
                     if (INL == LSE_IN_LEVELMAJOR) v[t] = a.in[((int64_t)(col >> 1) * n + tile_base + s_t) * 2 + (col & 1)];
                     else v[t] = a.in[(tile_base + s_t) * KIN + col];
                 }
-                split_pair<MS>((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4], v[5], v[6], v[7]}, nI, ib[nb]);
+                if constexpr (CT == 2) {
+                    split_pair<MS>((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4 * CT - 4], v[4 * CT - 3], v[4 * CT - 2], v[4 * CT - 1]}, nI, ib[nb]);
+                } else {
+                    uint32_t hi[2], mid[2], lo[2];
+                    split_half<true>((f32x4){v[0], v[1], v[2], v[3]}, nI, hi, mid, lo);
+                    ib[nb][0] = (u32x4){hi[0], hi[1], mid[0], mid[1]};
+                    ib[nb][1] = (u32x4){hi[0], hi[1], hi[0], hi[1]};
+                    ib[nb][2] = (u32x4){lo[0], lo[1], mid[0], mid[1]};
+                }
             }
         }
 #pragma unroll
         for (int mb = 0; mb < HB; ++mb) {
             u32x4 ga[3];
-            tr_block(mb, ga);
+            tr_block(mb, true, ga);
 #pragma unroll
-            for (int nb = 0; nb < KB0; ++nb) acc0[mb][nb] = mfma6(ga, ib[nb], acc0[mb][nb]);
+            for (int nb = 0; nb < KB0; ++nb) acc0[mb][nb] = wg_mfma(ga, ib[nb], acc0[mb][nb]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- dIn = W0^T dH0
