@@ -1519,6 +1519,7 @@ int launch_bwd3(const MlpArgs &a, hipStream_t st)
     switch ((int)lse::option("mlp_bwd3_cfg")) {      // CT * 100 + NW
     case 112: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 12>(a, st);
     case 108: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 8>(a, st);
+    case 204: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 4>(a, st);      // one wave per SIMD, 512 registers, free scheduling
     default: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 8>(a, st);
     }
 }

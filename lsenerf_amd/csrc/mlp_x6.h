@@ -606,9 +606,13 @@ struct X6Bwd {
 // waves fit a SIMD; the weight gradients then sum over 16 samples per product and use the k = 16 form (three MFMAs on two-piece
 // windows) -- the same matrix-core cycles per sample.
 template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES, int CT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs a)
 {
     using C = X6Bwd<KIN, NHL, CT, NW>;
+#define LSE_X6_SB()                                        \
+    do {                                                   \
+        if constexpr (NW > 4) __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
     constexpr int TS = 16 * CT, HB = 4, WIDTH = 64, S0 = C::S0, KB0 = KIN / 16;
     constexpr bool MS = (KIN == 32);      // remainder MFMAs on pairs of row blocks (base) / on single blocks (head: fewer live registers)
     static_assert((KIN == 16 && NHL == 2 && INL == LSE_IN_ROWMAJOR) || (KIN == 32 && NHL == 1), "head or base shape");
@@ -947,10 +951,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                             m0[ct] |= (h[b][ct][r] > 0.f ? 1u : 0u) << (4 * rb + r);
                         }
                     split_block_valu(s2, b, h[b], x);
-                    if constexpr (!MS) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!MS) LSE_X6_SB();
                 }
                 split_blocks(s2, h[0], h[1], x);
-                __builtin_amdgcn_sched_barrier(0);
+                LSE_X6_SB();
             }
         }
         if constexpr (NHL == 2) {
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                     split_block_valu(s2, b, h[b], x1);
                     if constexpr (!MS) {
                         write_buf_rb(rb, x1);
-                        __builtin_amdgcn_sched_barrier(0);
+                        LSE_X6_SB();
                     }
                 }
                 split_blocks(s2, h[0], h[1], x1);
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                     write_buf_rb(2 * s2, x1);
                     write_buf_rb(2 * s2 + 1, x1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                LSE_X6_SB();
             }
         } else {
 #pragma unroll
@@ -1010,12 +1014,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
         {
             u32x4 ga[3];
             tr_small(true, ga);
+            u32x4 hb[2][3];
+            tr_block(0, false, hb[0]);
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
-                u32x4 hb[3];
-                tr_block(kb, false, hb);
-                accO[0][kb] = wg_mfma(ga, hb, accO[0][kb]);
-                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 1 < HB) tr_block(kb + 1, false, hb[(kb + 1) & 1]);
+                accO[0][kb] = wg_mfma(ga, hb[kb & 1], accO[0][kb]);
+                LSE_X6_SB();
             }
         }
         lds_sync();
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                 split_block_valu(s2, b, dh[b], x);
                 if constexpr (!MS) {
                     write_buf_rb(rb, x);
-                    __builtin_amdgcn_sched_barrier(0);
+                    LSE_X6_SB();
                 }
             }
             split_blocks(s2, dh[0], dh[1], x);
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                 write_buf_rb(2 * s2, x);
                 write_buf_rb(2 * s2 + 1, x);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            LSE_X6_SB();
         }
         if constexpr (NHL == 2) {
             lds_sync();
@@ -1101,12 +1106,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                         hb[1] = (u32x4){hi[0], hi[1], hi[0], hi[1]};
                         hb[2] = (u32x4){lo[0], lo[1], mid[0], mid[1]};
                     }
+                    u32x4 ga[2][3];          // operand of block mb + 1 requested before the products of block mb are issued
+                    tr_block(0, true, ga[0]);
 #pragma unroll
                     for (int mb = 0; mb < HB; ++mb) {
-                        u32x4 ga[3];
-                        tr_block(mb, true, ga);
-                        acc1[mb][nb] = wg_mfma(ga, hb, acc1[mb][nb]);
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (mb + 1 < HB) tr_block(mb + 1, true, ga[(mb + 1) & 1]);
+                        acc1[mb][nb] = wg_mfma(ga[mb & 1], hb, acc1[mb][nb]);
+                        LSE_X6_SB();
                     }
                 }
             }
@@ -1136,7 +1142,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                         PiecesB<HB> y1[CT];
                         split_block_valu(s2, b, d0[b], y1);
                         write_buf_rb(cb, y1);
-                        __builtin_amdgcn_sched_barrier(0);
+                        LSE_X6_SB();
                     }
                 }
                 if constexpr (MS) {
@@ -1145,7 +1151,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                     write_buf_rb(2 * s2, y);
                     write_buf_rb(2 * s2 + 1, y);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                LSE_X6_SB();
             }
             read_buf_own(x);         // dH0 pieces (B operand of dIn)
         }
@@ -1236,13 +1242,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
                 }
             }
         }
+        {
+            u32x4 ga[2][3];
+            tr_block(0, true, ga[0]);
 #pragma unroll
-        for (int mb = 0; mb < HB; ++mb) {
-            u32x4 ga[3];
-            tr_block(mb, true, ga);
+            for (int mb = 0; mb < HB; ++mb) {
+                if (mb + 1 < HB) tr_block(mb + 1, true, ga[(mb + 1) & 1]);
 #pragma unroll
-            for (int nb = 0; nb < KB0; ++nb) acc0[mb][nb] = wg_mfma(ga, ib[nb], acc0[mb][nb]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int nb = 0; nb < KB0; ++nb) acc0[mb][nb] = wg_mfma(ga[mb & 1], ib[nb], acc0[mb][nb]);
+                LSE_X6_SB();
+            }
         }
         // ---- dIn = W0^T dH0
         if (a.d_in) {
@@ -1258,7 +1267,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_bwd3_kernel(MlpArgs a)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) di[ct] = mfma6(wa, x[ct].p[s], di[ct]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                LSE_X6_SB();
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     if (!valid[ct]) continue;
