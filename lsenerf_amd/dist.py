@@ -8,6 +8,10 @@ Occupancy grids stay replicated without DDP's per-forward buffer broadcast: ``LS
 cells and jitter from its OWN generator, re-seeded from ``(base seed, step)`` at every update, so every rank (whatever
 its global seed, R:train.py:104 seeds by rank) refreshes the same cells with the same positions from the same
 parameters; ``check_grid_consistency`` asserts it (rehearsed in tools/dp_rehearsal.py and tests/test_dist_cpu.py).
+"The same parameters give the same densities" holds to the last bit on one GPU in a quiet process; with several processes
+sharing a GPU the rehearsal saw ~0.3 % of the refreshes differ in the last bits of a few hash features, so
+``attach_grid_sync`` additionally broadcasts rank 0's ``occs`` / ``binaries`` after every refresh (33.5 + 8.4 MB once per 16
+steps: what DDP's buffer broadcast does on every forward, R:lse_nerf/lse_pipeline.py:97).
 
 Backend-agnostic: the same code runs on gloo/CPU tensors, which is how the world_size-2 tests exercise it.
 """
@@ -244,6 +248,23 @@ def check_grid_consistency(estimator) -> bool:
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
         ok = ok and bool(same.item())
     return ok
+
+
+def sync_grid(estimator, src: int = 0) -> None:
+    """Rank ``src``'s occupancy state replaces every other rank's (``occs`` fp32, ``binaries`` bool)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    dist.broadcast(estimator.occs, src=src)
+    b8 = estimator.binaries.view(torch.uint8) if estimator.binaries.dtype == torch.bool else estimator.binaries
+    dist.broadcast(b8, src=src)
+    if hasattr(estimator, "_occ_mean_host"):
+        estimator._occ_mean_host = None
+
+
+def attach_grid_sync(estimator, src: int = 0):
+    """Broadcast the grid from rank ``src`` after every refresh of ``estimator`` (its ``after_update_hook``)."""
+    estimator.after_update_hook = lambda: sync_grid(estimator, src)
+    return estimator
 
 
 def broadcast_params(flat_data: torch.Tensor, src: int = 0):

@@ -189,6 +189,9 @@ class LSEOccGridEstimator(nn.Module):
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre).reshape(1).contiguous()
         ops.occ_binarize(self.occs, thre, self._binaries_u8().view(-1))
         self._occ_mean_host = None
+        hook = getattr(self, "after_update_hook", None)      # data parallel: dist.attach_grid_sync
+        if hook is not None:
+            hook()
 
     def mark_all_occupied(self, value: float = 1.0) -> None:
         """Benchmark helper: the 'grid fully occupied' regime of training steps < 256."""

@@ -378,9 +378,17 @@ def _grid_rng_worker(rank, world, port, out):
         same.append(ok)
     consistent = ldist.check_grid_consistency(est)
     est.occs[0] += float(rank)                            # and the checker notices a divergence
+    est.binaries.view(-1)[3] = bool(rank)
     broken = ldist.check_grid_consistency(est)
+    ldist.sync_grid(est)                                  # ... which the broadcast of rank 0's grid repairs
+    repaired = ldist.check_grid_consistency(est)
+    # attach_grid_sync: the hook runs at the end of every refresh
+    ldist.attach_grid_sync(est)
+    est.occs[5] -= float(rank)                            # (the refresh itself runs HIP kernels: the hook is called directly here)
+    est.after_update_hook()
+    hooked = ldist.check_grid_consistency(est)
     if rank == 1:
-        torch.save({"same": same, "consistent": consistent, "broken": broken}, out)
+        torch.save({"same": same, "consistent": consistent, "broken": broken, "repaired": repaired, "hooked": hooked}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -391,6 +399,7 @@ def test_occupancy_refresh_is_rank_independent(tmp_path):
     got = torch.load(out)
     assert got["same"] == [True, True]
     assert got["consistent"] is True and got["broken"] is False
+    assert got["repaired"] is True and got["hooked"] is True
 
 
 def test_shard_rays_rejects_uneven_splits():
