@@ -167,7 +167,9 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
  *                     levels batched into one cache pass (default); 1 = one cache pass per level; 0 = 16-lanes-per-sample kernel
  *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 16)
- *   gran          cache slot size of impl 1: 2 = 32-B sectors x 512 slots (default), 3 = 64-B lines x 256 slots
+ *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2, default) =
+ *                     512 sector slots PAIRED by 64-B line, flushed in slot order -- a float-atomic request costs the same for 4 .. 64
+ *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 4)
  *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)

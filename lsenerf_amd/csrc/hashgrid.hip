@@ -665,7 +665,13 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
     }
 }
 
-template <bool WITH_DX, int kSlots, int kEntLog2>
+// kPair: the memory-side units charge a float-atomic REQUEST per 64-byte LINE, whatever part of it the request covers
+// (tools/micro/atomic_gran.hip: 21 G requests/s for 4 ... 64 contiguous bytes, half of that for 128).  With 32-byte slots a line
+// whose two sectors were both touched is flushed as two requests.  kPair hashes the LINE to a pair of neighbouring slots (even /
+// odd sector) and builds the flush list by scanning the keys in slot order, so sibling sectors sit in neighbouring 8-lane groups
+// of one flush instruction and go out as ONE contiguous 64-byte request; the scan also replaces the per-corner list appends of
+// the insert path (fewer instructions per pass).
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -677,6 +683,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
     constexpr int kPay = 2 * kEnt;             // payload floats per slot = lanes per slot in the flush
     constexpr int kSlotBits = 31 - __builtin_clz((unsigned)kSlots);
     constexpr int kChunk = 64 * kRounds;
+    constexpr int kStep = kPair ? 2 : 1;        // second probe: the next slot of the same parity
     __shared__ uint32_t s_key[4][kSlots];
     __shared__ float s_val[4][kSlots * kPay];
     __shared__ uint16_t s_list[4][kSlots];      // occupied slots
@@ -733,7 +740,13 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 // collisions on ray-shaped line sets, tools/sim_hash_bwd_requests.py)
                 uint32_t slot[8], old[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) slot[c] = (__umul24(gi[c] >> kEntLog2, 0x9E3779u) >> (24 - kSlotBits)) & (kSlots - 1);
+                for (int c = 0; c < 8; ++c) {
+                    if constexpr (kPair)
+                        slot[c] = (((__umul24(gi[c] >> (kEntLog2 + 1), 0x9E3779u) >> (25 - kSlotBits)) & (kSlots / 2 - 1)) << 1) |
+                                  ((gi[c] >> kEntLog2) & 1u);
+                    else
+                        slot[c] = (__umul24(gi[c] >> kEntLog2, 0x9E3779u) >> (24 - kSlotBits)) & (kSlots - 1);
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (gi[c] >> kEntLog2) : kNoLine);
@@ -745,12 +758,14 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const bool claim = act && old[c] == kNoLine;
-                    const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
-                    if (cm) {
-                        if (claim)
-                            list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                (uint16_t)slot[c];
-                        used += __builtin_popcountll(cm);
+                    if constexpr (!kPair) {
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                        if (cm) {
+                            if (claim)
+                                list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                    (uint16_t)slot[c];
+                            used += __builtin_popcountll(cm);
+                        }
                     }
                     okc[c] = claim || (act && old[c] == (gi[c] >> kEntLog2));
                     to_mem[c] = act && !okc[c];
@@ -764,20 +779,22 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                         uint32_t old2[8];
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + 1) & (kSlots - 1)] : dummy32, kNoLine,
+                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + kStep) & (kSlots - 1)] : dummy32, kNoLine,
                                               to_mem[c] ? (gi[c] >> kEntLog2) : kNoLine);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
                             const bool claim = to_mem[c] && old2[c] == kNoLine;
-                            const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
-                            if (cm) {
-                                if (claim)
-                                    list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                        (uint16_t)((slot[c] + 1) & (kSlots - 1));
-                                used += __builtin_popcountll(cm);
+                            if constexpr (!kPair) {
+                                const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
+                                if (cm) {
+                                    if (claim)
+                                        list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
+                                            (uint16_t)((slot[c] + kStep) & (kSlots - 1));
+                                    used += __builtin_popcountll(cm);
+                                }
                             }
                             if (claim || (to_mem[c] && old2[c] == (gi[c] >> kEntLog2))) {
-                                slot[c] = (slot[c] + 1) & (kSlots - 1);
+                                slot[c] = (slot[c] + kStep) & (kSlots - 1);
                                 okc[c] = true;
                                 to_mem[c] = false;
                             }
@@ -821,6 +838,17 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             // flush: 16 lanes per line, 4 lines per instruction, 16 lines per trip (loads first)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (kPair) {      // occupied slots in slot order: sibling sectors of a line become list neighbours
+#pragma unroll
+                for (int s0 = 0; s0 < kSlots; s0 += 64) {
+                    const bool occ = key[s0 + lane] != kNoLine;
+                    const uint64_t om = __builtin_amdgcn_ballot_w64(occ);
+                    if (occ) list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0))] = (uint16_t)(s0 + lane);
+                    used += __builtin_popcountll(om);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             constexpr int kPer = 64 / kPay;   // slots per flush instruction
             const int sub = lane & (kPay - 1);
             for (uint32_t e0 = lane / kPay; e0 < used; e0 += 4 * kPer) {
@@ -1044,7 +1072,7 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     if (!o) return;
     o->impl = 2;           // lane-per-sample + LDS sector cache, run ends of several levels batched per cache pass
     o->stage_max = 16;     // impl 2: a level ending more runs than this per wave passes unstaged when the queue is empty
-    o->gran = 2;           // 512 slots of one 32-B sector
+    o->gran = 4;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line (2 = unpaired); impl 1: 2 / 3
     o->few_runs = 4;       // tuned on MI355X: 4..8 equal, 16 already slower
     o->second_probe = 1;   // extra probe rounds (next slot) before a corner goes to memory alone; pays wherever the kernel is
                            // bound by atomic requests (sphere rays 4.27 -> 3.86 ms), costs ~2 % where it is issue-bound
@@ -1075,7 +1103,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     if (opts) o = *opts;
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran == 2 || o.gran == 3, "lse_hash_bwd: opts.gran must be 2 or 3");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 4, "lse_hash_bwd: opts.gran must be 2, 3 or 4");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1103,6 +1131,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            return lse::check_launch("lse_hash_bwd");
+        }
         if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
         else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
@@ -1118,7 +1153,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #define LSE_LAUNCH_CACHED(DX, SLOTS, ENTLOG2)                                                                          \
     hipLaunchKernelGGL((hash_bwd_cached_kernel<DX, SLOTS, ENTLOG2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2, \
                        tb2, dtable, dx, n, dbg, few_runs, second_probe)
-        if (gran == 2) {   // 512 slots of one 32-B sector
+        if (gran != 3) {   // 512 slots of one 32-B sector (gran 4 = the pairing of impl 2: plain sectors here)
             if (dx) LSE_LAUNCH_CACHED(true, 512, 2);
             else LSE_LAUNCH_CACHED(false, 512, 2);
         } else {           // 256 slots of one 64-B line
