@@ -169,7 +169,8 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 16)
  *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2, default) =
  *                     512 sector slots PAIRED by 64-B line, flushed in slot order -- a float-atomic request costs the same for 4 .. 64
- *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request
+ *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request; 5 = the same with
+ *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size)
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 4)
  *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)

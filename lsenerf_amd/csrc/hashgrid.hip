@@ -1103,7 +1103,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     if (opts) o = *opts;
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 4, "lse_hash_bwd: opts.gran must be 2, 3 or 4");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 5, "lse_hash_bwd: opts.gran must be 2 .. 5");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1131,6 +1131,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        if (o.gran == 5) {      // the same with 256 slots: half the LDS, three workgroups per CU
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            return lse::check_launch("lse_hash_bwd");
+        }
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
