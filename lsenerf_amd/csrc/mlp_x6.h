@@ -846,6 +846,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                 }
     };
 
+    int brow_nx[CT] = {};
+    if (BIAS && a.row_bias_idx && t_begin < t_end) {
+        const int64_t b0 = t_begin * TS;
+        const int nr = (int)min((int64_t)TS, n - b0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) brow_nx[ct] = a.row_bias_idx[b0 + min(ct * 16 + j, nr - 1)];
+    }
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         const int64_t tile_base = tile * TS;
         const int n_rem = (int)min((int64_t)TS, n - tile_base);       // valid samples of this tile (wave-uniform, >= 1)
@@ -863,10 +870,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
         const float *rbase = a.row_bias;
         int brow[CT] = {};
         if constexpr (BIAS) {
-            if (a.row_bias_idx) {
-                const int32_t *idx_t = a.row_bias_idx + tile_base;
+            if (a.row_bias_idx) {       // this tile's rows were requested during the previous tile; request the next tile's now
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) brow[ct] = idx_t[sl[ct]];
+                for (int ct = 0; ct < CT; ++ct) brow[ct] = brow_nx[ct];
+                if (tile + 1 < t_end) {
+                    const int64_t nb_ = tile_base + TS;
+                    const int nr = (int)min((int64_t)TS, n - nb_);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) brow_nx[ct] = a.row_bias_idx[nb_ + min(ct * 16 + j, nr - 1)];
+                }
             } else {
                 rbase = a.row_bias + tile_base * WIDTH;
 #pragma unroll
@@ -1024,6 +1036,22 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         lds_sync();
+        // (32-input shape) the layer-0 input in operand layout for dW0 -- lane = input column, slots = samples -- is read from
+        // memory; requested here so that the loads land under the products below instead of in front of dW0
+        float vin[(KIN == 32) ? KB0 : 1][4 * CT];
+        if constexpr (KIN == 32) {
+#pragma unroll
+            for (int nb = 0; nb < KB0; ++nb) {
+                const int col = 16 * nb + j;
+#pragma unroll
+                for (int t = 0; t < 4 * CT; ++t) {
+                    int s_t = 16 * (t >> 2) + 4 * q + (t & 3);
+                    s_t = s_t < n_rem ? s_t : n_rem - 1;
+                    if (INL == LSE_IN_LEVELMAJOR) vin[nb][t] = a.in[((int64_t)(col >> 1) * n + tile_base + s_t) * 2 + (col & 1)];
+                    else vin[nb][t] = a.in[(tile_base + s_t) * KIN + col];
+                }
+            }
+        }
         // ---- dH_last = Wo^T G_out (16 rows of Wo: k = 16), masked; pieces to the tile and into registers
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1064,28 +1092,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                 PiecesB16 xin16[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
-                int trow[CT][4] = {};      // bias rows of samples 16ct + 4q + r
+                // bias rows of samples 16ct + 4q + r: lane 4q + r of this lane's 16-lane group holds that sample's row
+                int trow[CT][4] = {};
                 if constexpr (BIAS) {
-                    if (a.row_bias_idx) {
-                        const int32_t *idx_t = a.row_bias_idx + tile_base;
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
+                    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) trow[ct][r] = idx_t[min(16 * ct + 4 * q + r, n_rem - 1)];
-                    } else {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) trow[ct][r] = min(16 * ct + 4 * q + r, n_rem - 1);
-                    }
+                        for (int r = 0; r < 4; ++r) trow[ct][r] = __shfl(brow[ct], 4 * q + r, 16);
                 }
+                // bias^T of all four blocks requested at once (one exposed latency instead of four)
+                f32x4 t0a[HB][CT];
+#pragma unroll
+                for (int nb = 0; nb < HB; ++nb)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t0a[nb][ct][r] = BIAS ? rbase[(unsigned)(trow[ct][r] * WIDTH + 16 * nb + j)] : 0.f;
 #pragma unroll
                 for (int nb = 0; nb < HB; ++nb) {
                     f32x4 t0[CT];
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) t0[ct][r] = BIAS ? rbase[(unsigned)(trow[ct][r] * WIDTH + 16 * nb + j)] : 0.f;
+                    for (int ct = 0; ct < CT; ++ct) t0[ct] = t0a[nb][ct];
                     u32x4 wc[3];
                     combos16_lds([&](int p) { return lds_read8(imgW0 + (p * C::W0_PIECE + 512 * nb + sm_j)); }, wc);
 #pragma unroll
@@ -1222,15 +1249,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             lds_sync();
 #pragma unroll
             for (int nb = 0; nb < KB0; ++nb) {
-                float v[4 * CT];
-                const int col = 16 * nb + j;
-#pragma unroll
-                for (int t = 0; t < 4 * CT; ++t) {
-                    int s_t = 16 * (t >> 2) + 4 * q + (t & 3);
-                    s_t = s_t < n_rem ? s_t : n_rem - 1;
-                    if (INL == LSE_IN_LEVELMAJOR) v[t] = a.in[((int64_t)(col >> 1) * n + tile_base + s_t) * 2 + (col & 1)];
-                    else v[t] = a.in[(tile_base + s_t) * KIN + col];
-                }
+                const float (&v)[4 * CT] = vin[nb];
                 if constexpr (CT == 2) {
                     split_pair<MS>((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4 * CT - 4], v[4 * CT - 3], v[4 * CT - 2], v[4 * CT - 1]}, nI, ib[nb]);
                 } else {
