@@ -407,6 +407,13 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 
     f32x4 raw_nx[CT][KIN / 16];
     if (t_begin < t_end) load_in_x6<KIN, INL, CT>(a, t_begin, j, q, raw_nx);
+    int idx_nx[CT] = {};
+    if (a.row_bias && a.row_bias_idx && t_begin < t_end) {
+        const int64_t b0 = t_begin * TS;
+        const int nr = (int)min((int64_t)TS, n - b0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) idx_nx[ct] = a.row_bias_idx[b0 + min(ct * 16 + j, nr - 1)];
+    }
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         const int64_t tile_base = tile * TS;
         const int n_rem = (int)min((int64_t)TS, n - tile_base);
@@ -422,11 +429,29 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int b = 0; b < KIN / 16; ++b) raw[ct][b] = raw_nx[ct][b];
+        // (density head) the selector is requested here, not behind the last product of the tile
+        uint32_t selv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) selv[ct] = (a.sigma_out && a.selector && q == 0) ? (uint32_t)a.selector[tile_base + sl[ct]] : 1u;
         f32x4 h[HB][CT];
         if (a.row_bias) {
+            int64_t rowv[CT];
+            if (a.row_bias_idx) {      // this tile's rows were requested during the previous tile; the next tile's are requested now
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) rowv[ct] = idx_nx[ct];
+                if (tile + 1 < t_end) {
+                    const int64_t nb_ = tile_base + TS;
+                    const int nr = (int)min((int64_t)TS, n - nb_);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) idx_nx[ct] = a.row_bias_idx[nb_ + min(ct * 16 + j, nr - 1)];
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) rowv[ct] = tile_base + sl[ct];
+            }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int64_t row = a.row_bias_idx ? (int64_t)a.row_bias_idx[tile_base + sl[ct]] : tile_base + sl[ct];
+                const int64_t row = rowv[ct];
 #pragma unroll
                 for (int rb = 0; rb < HB; ++rb)
                     h[rb][ct] = *reinterpret_cast<const f32x4 *>(a.row_bias + row * WIDTH + 16 * rb + 4 * q);
@@ -495,10 +520,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
             if (valid[ct]) {
                 if (oc == 16) *reinterpret_cast<f32x4 *>(out_t + (unsigned)(sl[ct] * 16 + 4 * q)) = o[0][ct];
                 else if (q == 0) *reinterpret_cast<f32x4 *>(out_t + (unsigned)(sl[ct] * 4)) = o[0][ct];
-                if (a.sigma_out && q == 0) {
-                    const bool in_bounds = a.selector == nullptr || a.selector[tile_base + sl[ct]] != 0;
-                    a.sigma_out[tile_base + sl[ct]] = in_bounds ? a.density_scale * expf(o[0][ct][0]) : 0.f;
-                }
+                if (a.sigma_out && q == 0) a.sigma_out[tile_base + sl[ct]] = selv[ct] != 0u ? a.density_scale * expf(o[0][ct][0]) : 0.f;
             }
         }
     }
@@ -887,30 +909,38 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
         }
         f32x4 g[CT];
         {
+            // every load of the tile is issued before the first use (no load behind a branch on another load's value)
             const float *dout_t = a.d_out + tile_base * oc;
             const float *out_t = a.out ? a.out + tile_base * oc : nullptr;
+            f32x4 ovv[CT];
+            float dsgv[CT], o0v[CT];
+            uint32_t selv[CT];
+            const bool lane_sig = a.d_sigma != nullptr && q == 0;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int slc = sl[ct];
-                f32x4 ov = (f32x4){0.f, 0.f, 0.f, 0.f};
+                ovv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (oc == 16) g[ct] = *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(slc * 16 + 4 * q));
                 else g[ct] = (q == 0) ? *reinterpret_cast<const f32x4 *>(dout_t + (unsigned)(slc * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (need_out) {
-                    if (oc == 16) ov = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 16 + 4 * q));
-                    else if (q == 0) ov = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 4));
+                    if (oc == 16) ovv[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 16 + 4 * q));
+                    else if (q == 0) ovv[ct] = *reinterpret_cast<const f32x4 *>(out_t + (unsigned)(slc * 4));
                 }
-                float dsg = 0.f;
-                if (a.d_sigma && q == 0) {
-                    const bool in_bounds = a.selector == nullptr || a.selector[tile_base + slc] != 0;
-                    if (!need_out) ov[0] = out_t[(unsigned)(slc * oc)];
-                    dsg = in_bounds ? a.d_sigma[tile_base + slc] : 0.f;
-                }
+                dsgv[ct] = lane_sig ? a.d_sigma[tile_base + slc] : 0.f;
+                o0v[ct] = (lane_sig && !need_out) ? out_t[(unsigned)(slc * oc)] : 0.f;
+                selv[ct] = (lane_sig && a.selector) ? (uint32_t)a.selector[tile_base + slc] : 1u;
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 ov = ovv[ct];
+                if (lane_sig && !need_out) ov[0] = o0v[ct];
+                const float dsg = selv[ct] != 0u ? dsgv[ct] : 0.f;
                 const float x0 = fminf(fmaxf(ov[0], -15.f), 15.f);
                 if (need_out) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g[ct][r] = g[ct][r] * ov[r] * (1.f - ov[r]);
                 }
-                if (a.d_sigma && q == 0) g[ct][0] += dsg * a.density_scale * expf(x0);
+                if (lane_sig) g[ct][0] += dsg * a.density_scale * expf(x0);
                 if (!valid[ct]) g[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
