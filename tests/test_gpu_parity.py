@@ -495,6 +495,65 @@ def test_mlp_third_generation_bf16_pieces(monkeypatch, recompute_all, fwd_impl):
         _lib.set_option("mlp_fwd_impl", old)
 
 
+@pytest.mark.parametrize("pattern", ["short", "mixed", "tile_aligned", "long"])
+def test_mlp_head_view_bias_column_row_patterns(pattern):
+    """The head as the field calls it (first-layer view: leading dimension 64, column offset 15, column 0 masked, compact 4-column
+    output): the per-row bias gradient rides in the free column of the dW0 product of the recomputing backward.  One product
+    covers two 16-sample column tiles, so only one row per 32-sample tile may use the column and every other row of the tile
+    takes the segmented scan -- exercised here with rows of 0..3, 0..100, exactly 16 / 32 / 48 and ~1000 samples.  Third- and
+    second-generation backward must agree to summation noise; both against a float64 network (relative L2: single ReLU-gate
+    flips are allowed to exist, see tests/util.py)."""
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed({"short": 1, "mixed": 2, "tile_aligned": 3, "long": 4}[pattern])
+    R = 400
+    if pattern == "short":
+        cnt = torch.randint(0, 4, (R,), generator=g)
+    elif pattern == "mixed":
+        cnt = torch.randint(0, 101, (R,), generator=g)
+    elif pattern == "tile_aligned":
+        cnt = torch.tensor([16, 32, 48, 0, 16, 16, 32])[torch.randint(0, 7, (R,), generator=g)]
+    else:
+        cnt = torch.randint(900, 1100, (40,), generator=g)
+        R = 40
+    N = int(cnt.sum())
+    ridx = torch.repeat_interleave(torch.arange(R), cnt)
+    packed = torch.stack([torch.cumsum(cnt, 0) - cnt, cnt], -1)
+    meta = ops.MlpMeta(16, 64, 2, _lib.LSE_ACT_SIGMOID, _lib.LSE_IN_ROWMAJOR, 64, 15, 1)
+    params = torch.randn(64 * 64 + 64 * 64 + 16 * 64, generator=g) * 0.15
+    x = torch.randn(N, 16, generator=g)
+    bias = torch.randn(R, 64, generator=g) * 0.3
+    w = torch.randn(N, 4, generator=g)
+    got = {}
+    for gen3 in (True, False):
+        ops.RECOMPUTE_ALL = gen3
+        try:
+            p = params.clone().cuda().requires_grad_(True)
+            xc = x.clone().cuda().requires_grad_(True)
+            b = bias.clone().cuda().requires_grad_(True)
+            out = ops.fused_mlp(p, xc, meta, N, b, ridx.int().cuda(), packed.cuda(), out_cols=4)
+            (out * w.cuda()).sum().backward()
+        finally:
+            ops.RECOMPUTE_ALL = True
+        got[gen3] = (out.detach().cpu(), p.grad.cpu(), xc.grad.cpu(), b.grad.cpu())
+    for a, c in zip(got[True], got[False]):
+        assert nmax_err(a, c) < 1e-5
+    assert torch.all(got[True][3][cnt == 0] == 0)
+    # float64 network
+    p64 = params.double().requires_grad_(True)
+    x64, b64 = x.double().requires_grad_(True), bias.double().requires_grad_(True)
+    msk = torch.ones(16, dtype=torch.float64)
+    msk[0] = 0
+    h = torch.relu(x64 @ (p64[:4096].view(64, 64)[:, 15:31] * msk).T + b64[ridx])
+    h = torch.relu(h @ p64[4096:8192].view(64, 64).T)
+    o = torch.sigmoid(h @ p64[8192:].view(16, 64).T)[:, :4]
+    (o * w.double()).sum().backward()
+    from tests.util import rel_l2
+    assert nmax_err(got[True][0], o.detach()) < TOL_FWD
+    for a, c in zip(got[True][1:], (p64.grad, x64.grad, b64.grad)):
+        assert rel_l2(a, c) < 10 * TOL_GRAD       # (a few thousand samples: one flipped ReLU gate is 1e-3 of the L2 norm)
+
+
 def test_mlp_row_bias_grad_many_short_rows():
     """Rows of 0..3 samples: several row boundaries inside every 16-sample tile of the fused bias-gradient scan."""
     ops = _ops()
