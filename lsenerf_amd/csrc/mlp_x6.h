@@ -18,7 +18,7 @@
 //   B of 16x16x32:    lane (col j, q = lane >> 4) holds k-slots 8q .. 8q+7 of its sample, two per 32-bit register.
 // With the k order  neuron(s, q, t) = 16 * (2s + (t >> 2)) + 4q + (t & 3)  (s = 32-wide k slab, t = slot inside the lane) a
 // lane's 8 slots of slab s are registers 0..3 of accumulator row blocks 2s and 2s+1 of the previous layer: layers chain in
-// registers, the only work between two layers is ReLU + cutting 16 floats into pieces (5.5 vector instructions each).
+// registers, the only work between two layers is ReLU + cutting 16 floats into pieces (on the matrix core, see split_pair).
 // Weights (A operands) are cut once per workgroup into LDS images in the same k order, one ds_read_b128 per lane and piece.
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -27,22 +27,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define LSE_MFMA_BF(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-constexpr uint32_t kTopHalves = 0x07060302u;      // v_perm_b32: (high 16 bits of src0) << 16 | high 16 bits of src1
-
-// two floats -> their three bf16 pieces, packed (x1's piece in the high half).  Truncation, not rounding: the remainders
-// are exact in f32 and the third piece is exactly representable.
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo)
-{
-    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(b1, b0, kTopHalves);
-    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
-    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(c1, c0, kTopHalves);
-    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), kTopHalves);
-}
-
-// host/device: one float -> piece p (0 hi, 1 mid, 2 lo) as a bf16 bit pattern (for the weight images)
+// one float -> piece p (0 hi, 1 mid, 2 lo) as a bf16 bit pattern, by truncation: the remainders are exact in f32 and the third
+// piece is exactly representable (weight images, cut once per workgroup)
 __device__ __forceinline__ uint32_t piece_of(float x, int p)
 {
     uint32_t b = __float_as_uint(x);
@@ -54,8 +40,8 @@ __device__ __forceinline__ uint32_t piece_of(float x, int p)
     return b >> 16;
 }
 
-// ---- cutting on the matrix core.  The vector-ALU route above costs 5.5 instructions per value and the kernels are bound by
-// exactly those instructions.  Instead:  hi = bf16(x) (v_cvt_pk_bf16_f32, two values per instruction, round to nearest), then
+// ---- cutting on the matrix core.  Cutting on the vector ALU (and / subtract / permute) costs 5.5 instructions per value and
+// made the kernels bound by exactly those instructions.  Instead:  hi = bf16(x) (v_cvt_pk_bf16_f32, two values per instruction, round to nearest), then
 // the REMAINDER x - hi is produced by one MFMA with the negated identity as the A operand and the packed hi pieces as B
 // (D = C - I * hi: the product is exact, and x - bf16(x) is exactly representable, so the MFMA returns it exactly); the same
 // again for mid; lo = bf16(second remainder).  8 values per lane (slots 0..3 = c0, 4..7 = c1 -- e.g. accumulator row blocks
@@ -81,21 +67,9 @@ __device__ __forceinline__ void neg_identity(int lane, u32x4 (&nI)[2])
 }
 
 // c0, c1 -> pieces o[hi, mid, lo]; c0 / c1 are consumed (they end as the third remainders)
-template <bool M = true, typename NI>
+template <typename NI>
 __device__ __forceinline__ void split_pair(f32x4 c0, f32x4 c1, const NI &nI, u32x4 (&o)[3])
 {
-    if constexpr (!M) {          // vector-ALU route (truncated pieces)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t hi, mid, lo;
-            if (w < 2) split2(c0[2 * w], c0[2 * w + 1], hi, mid, lo);
-            else split2(c1[2 * w - 4], c1[2 * w - 3], hi, mid, lo);
-            o[0][w] = hi;
-            o[1][w] = mid;
-            o[2][w] = lo;
-        }
-        return;
-    }
     o[0] = (u32x4){cvt_pk(c0[0], c0[1]), cvt_pk(c0[2], c0[3]), cvt_pk(c1[0], c1[1]), cvt_pk(c1[2], c1[3])};
     c0 = LSE_MFMA_BF(nI[0], o[0], c0);
     c1 = LSE_MFMA_BF(nI[1], o[0], c1);
@@ -106,14 +80,9 @@ __device__ __forceinline__ void split_pair(f32x4 c0, f32x4 c1, const NI &nI, u32
 }
 
 // four values per lane (k = 16 operands): pieces as 2-register halves
-template <bool M = true, typename NI>
+template <typename NI>
 __device__ __forceinline__ void split_half(f32x4 c0, const NI &nI, uint32_t (&hi)[2], uint32_t (&mid)[2], uint32_t (&lo)[2])
 {
-    if constexpr (!M) {
-        split2(c0[0], c0[1], hi[0], mid[0], lo[0]);
-        split2(c0[2], c0[3], hi[1], mid[1], lo[1]);
-        return;
-    }
     hi[0] = cvt_pk(c0[0], c0[1]);
     hi[1] = cvt_pk(c0[2], c0[3]);
     c0 = LSE_MFMA_BF(nI[0], ((u32x4){hi[0], hi[1], 0u, 0u}), c0);
@@ -133,44 +102,8 @@ struct PiecesB {
     u32x4 p[HB / 2][3];
 };
 
-template <int HB>
-__device__ __forceinline__ void split_acc(const f32x4 (&h)[HB], PiecesB<HB> &o)
-{
-#pragma unroll
-    for (int s = 0; s < HB / 2; ++s)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int rb = 2 * s + (w >> 1), r = 2 * (w & 1);
-            uint32_t a, b, c;
-            split2(h[rb][r], h[rb][r + 1], a, b, c);
-            o.p[s][0][w] = a;
-            o.p[s][1][w] = b;
-            o.p[s][2][w] = c;
-        }
-}
-
-// acc[rb] += W[rows 16rb.., :] * X for one column tile; img = LDS image [piece][rb][slab][64 lanes] of u32x4.
-template <int RB, int S>
-__device__ __forceinline__ void layer_x6(f32x4 (&acc)[RB], const u32x4 *img, const PiecesB<2 * S> &x, int lane)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const u32x4 ah = img[((0 * RB + rb) * S + s) * 64 + lane];
-            const u32x4 am = img[((1 * RB + rb) * S + s) * 64 + lane];
-            const u32x4 al = img[((2 * RB + rb) * S + s) * 64 + lane];
-            // smallest pieces first
-            acc[rb] = LSE_MFMA_BF(al, x.p[s][0], acc[rb]);
-            acc[rb] = LSE_MFMA_BF(ah, x.p[s][2], acc[rb]);
-            acc[rb] = LSE_MFMA_BF(am, x.p[s][1], acc[rb]);
-            acc[rb] = LSE_MFMA_BF(am, x.p[s][0], acc[rb]);
-            acc[rb] = LSE_MFMA_BF(ah, x.p[s][1], acc[rb]);
-            acc[rb] = LSE_MFMA_BF(ah, x.p[s][0], acc[rb]);
-        }
-}
-
-// the same for CT column tiles at once (the A pieces are read once)
+// acc[rb][ct] += W[rows 16rb.., :] * X for CT column tiles at once (the A pieces are read once); img = LDS image
+// [piece][rb][slab][64 lanes] of u32x4
 template <int RB, int S, int CT>
 __device__ __forceinline__ void layer_x6_ct(f32x4 (&acc)[RB][CT], const u32x4 *img, const PiecesB<2 * S> (&x)[CT], int lane)
 {
@@ -207,11 +140,11 @@ struct PiecesB16 {
     u32x4 c[3];
 };
 
-template <bool M = true, typename NI>
+template <typename NI>
 __device__ __forceinline__ void split_in16(const f32x4 v, const NI &nI, PiecesB16 &o)
 {
     uint32_t h[2], m[2], l[2];
-    split_half<M>(v, nI, h, m, l);
+    split_half(v, nI, h, m, l);
     o.c[0] = (u32x4){h[0], h[1], m[0], m[1]};
     o.c[1] = (u32x4){h[0], h[1], h[0], h[1]};
     o.c[2] = (u32x4){l[0], l[1], m[0], m[1]};
@@ -252,24 +185,6 @@ __device__ __forceinline__ void stage_chain_image(u32x4 *img, const float *W, in
         const int i = ln & 15, q = ln >> 4, row = 16 * rb + i;
         const float v0 = row < rows_real ? W[row * ld + kslot_chain(s, q, 2 * word)] : 0.f;
         const float v1 = row < rows_real ? W[row * ld + kslot_chain(s, q, 2 * word + 1)] : 0.f;
-        w32[e] = piece_of(v0, p) | (piece_of(v1, p) << 16);
-    }
-}
-
-// transposed chained layer (data gradient: A = W^T): out rows = columns of W (cols_real of them), k = rows of W
-template <int RB, int S>
-__device__ __forceinline__ void stage_chain_image_t(u32x4 *img, const float *W, int ld, int cols_real, int col_mask0,
-                                                    int k_real, int nthreads)
-{
-    uint32_t *w32 = reinterpret_cast<uint32_t *>(img);
-    for (int e = threadIdx.x; e < 3 * RB * S * 64 * 4; e += nthreads) {
-        const int word = e & 3, ln = (e >> 2) & 63, rest = e >> 8;
-        const int s = rest % S, rb = (rest / S) % RB, p = rest / (S * RB);
-        const int i = ln & 15, q = ln >> 4, col = 16 * rb + i;
-        const int k0 = kslot_chain(s, q, 2 * word), k1 = kslot_chain(s, q, 2 * word + 1);
-        const bool ok = col < cols_real && !(col_mask0 && col == 0);
-        const float v0 = (ok && k0 < k_real) ? W[k0 * ld + col] : 0.f;
-        const float v1 = (ok && k1 < k_real) ? W[k1 * ld + col] : 0.f;
         w32[e] = piece_of(v0, p) | (piece_of(v1, p) << 16);
     }
 }
@@ -356,12 +271,12 @@ __device__ __forceinline__ void first_layer_x6(f32x4 (&h)[4][CT], const u32x4 *i
     if constexpr (KIN == 16) {
         PiecesB16 x[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, x[ct]);
+        for (int ct = 0; ct < CT; ++ct) split_in16(raw[ct][0], nI, x[ct]);
         layer16_x6_ct<4, CT>(h, img0, x, lane);
     } else {
         PiecesB<2> x[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) split_pair<true>(raw[ct][0], raw[ct][1], nI, x[ct].p[0]);
+        for (int ct = 0; ct < CT; ++ct) split_pair(raw[ct][0], raw[ct][1], nI, x[ct].p[0]);
         layer_x6_ct<4, 1, CT>(h, img0, x, lane);
     }
 }
@@ -480,7 +395,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) split_pair<true>(h[2 * s2][ct], h[2 * s2 + 1][ct], nI, x[ct].p[s2]);
+            for (int s2 = 0; s2 < 2; ++s2) split_pair(h[2 * s2][ct], h[2 * s2 + 1][ct], nI, x[ct].p[s2]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hidden layer
         if constexpr (NHL == 2) {
@@ -502,7 +417,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) split_pair<true>(h2[2 * s2][ct], h2[2 * s2 + 1][ct], nI, x[ct].p[s2]);
+                for (int s2 = 0; s2 < 2; ++s2) split_pair(h2[2 * s2][ct], h2[2 * s2 + 1][ct], nI, x[ct].p[s2]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- output layer
@@ -596,13 +511,7 @@ __device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3],
 struct Halves {
     u32x2 p[3];
 };
-__device__ __forceinline__ void combos16(const Halves &w, u32x4 (&c)[3])
-{
-    c[0] = (u32x4){w.p[0][0], w.p[0][1], w.p[0][0], w.p[0][1]};      // (hi  | hi)
-    c[1] = (u32x4){w.p[1][0], w.p[1][1], w.p[2][0], w.p[2][1]};      // (mid | lo)
-    c[2] = (u32x4){w.p[0][0], w.p[0][1], w.p[1][0], w.p[1][1]};      // (hi  | mid)
-}
-// the same three operands from six 8-byte LDS reads (no register shuffling): rd(p) reads the halves of piece p
+// the three A-side operands (hi|hi), (mid|lo), (hi|mid) from 8-byte LDS reads: rd(p) reads the halves of piece p
 template <typename F>
 __device__ __forceinline__ void combos16_lds(F rd, u32x4 (&c)[3])
 {
@@ -775,18 +684,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             return LSE_MFMA_BF(a3[0], b3[0], c);
         }
     };
-    // write the pieces of one column tile (accumulator layout, 4 row blocks) into the [32 x 64] tile
-    auto write_buf = [&](int ct, const PiecesB<HB> &x) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int rb = 0; rb < HB; ++rb)
-                lds_write8(buf + (p * C::BUF_PIECE + 2048 * ct + so_j[rb]), x.p[rb >> 1][p][2 * (rb & 1)], x.p[rb >> 1][p][2 * (rb & 1) + 1]);
-    };
     // f32x4 (4 consecutive columns of one sample) -> plain pieces
     auto split4 = [&](const f32x4 v, Halves &h) {
         uint32_t hi[2], mid[2], lo[2];
-        split_half<true>(v, nI, hi, mid, lo);
+        split_half(v, nI, hi, mid, lo);
         h.p[0] = (u32x2){hi[0], hi[1]};
         h.p[1] = (u32x2){mid[0], mid[1]};
         h.p[2] = (u32x2){lo[0], lo[1]};
@@ -828,17 +729,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
     auto split_blocks = [&](int s2, const f32x4 (&c0)[CT], const f32x4 (&c1)[CT], PiecesB<HB> (&x)[CT]) {
         if constexpr (MS) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) split_pair<true>(c0[ct], c1[ct], nI, x[ct].p[s2]);
+            for (int ct = 0; ct < CT; ++ct) split_pair(c0[ct], c1[ct], nI, x[ct].p[s2]);
         }
     };
     // head shape (registers are scarce): one block at a time, as soon as it is complete -- the same two remainder MFMAs per
     // block as the paired form (the unused half of the B operand is zero)
-    auto split_block_valu = [&](int s2, int b, const f32x4 (&c)[CT], PiecesB<HB> (&x)[CT]) {
+    auto split_block_single = [&](int s2, int b, const f32x4 (&c)[CT], PiecesB<HB> (&x)[CT]) {
         if constexpr (!MS) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 uint32_t hi[2], mid[2], lo[2];
-                split_half<true>(c[ct], nI, hi, mid, lo);
+                split_half(c[ct], nI, hi, mid, lo);
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
                     x[ct].p[s2][0][2 * b + w2] = hi[w2];
@@ -952,10 +853,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             u32x4 xin[CT][3];
             if constexpr (KIN == 16) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
+                for (int ct = 0; ct < CT; ++ct) split_in16(raw[ct][0], nI, xin16[ct]);
             } else {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) split_pair<MS>(raw[ct][0], raw[ct][1], nI, xin[ct]);
+                for (int ct = 0; ct < CT; ++ct) split_pair(raw[ct][0], raw[ct][1], nI, xin[ct]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -992,7 +893,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                             h[b][ct][r] = relu_bits(h[b][ct][r]);
                             m0[ct] |= (h[b][ct][r] > 0.f ? 1u : 0u) << (4 * rb + r);
                         }
-                    split_block_valu(s2, b, h[b], x);
+                    split_block_single(s2, b, h[b], x);
                     if constexpr (!MS) LSE_X6_SB();
                 }
                 split_blocks(s2, h[0], h[1], x);
@@ -1024,7 +925,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                             h[b][ct][r] = relu_bits(h[b][ct][r]);
                             m1[ct] |= (h[b][ct][r] > 0.f ? 1u : 0u) << (4 * rb + r);
                         }
-                    split_block_valu(s2, b, h[b], x1);
+                    split_block_single(s2, b, h[b], x1);
                     if constexpr (!MS) {
                         write_buf_rb(rb, x1);
                         LSE_X6_SB();
@@ -1101,7 +1002,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dh[b][ct][r] = ((m >> (4 * rb + r)) & 1u) ? dh[b][ct][r] : 0.f;
                 }
-                split_block_valu(s2, b, dh[b], x);
+                split_block_single(s2, b, dh[b], x);
                 if constexpr (!MS) {
                     write_buf_rb(rb, x);
                     LSE_X6_SB();
@@ -1121,7 +1022,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             {
                 PiecesB16 xin16[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) split_in16<true>(raw[ct][0], nI, xin16[ct]);
+                for (int ct = 0; ct < CT; ++ct) split_in16(raw[ct][0], nI, xin16[ct]);
                 // bias rows of samples 16ct + 4q + r: lane 4q + r of this lane's 16-lane group holds that sample's row
                 int trow[CT][4] = {};
                 if constexpr (BIAS) {
@@ -1155,10 +1056,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                     }
                     u32x4 hb[3];
                     if constexpr (CT == 2) {
-                        split_pair<true>(t0[0], t0[CT - 1], nI, hb);
+                        split_pair(t0[0], t0[CT - 1], nI, hb);
                     } else {
                         uint32_t hi[2], mid[2], lo[2];
-                        split_half<true>(t0[0], nI, hi, mid, lo);
+                        split_half(t0[0], nI, hi, mid, lo);
                         hb[0] = (u32x4){hi[0], hi[1], mid[0], mid[1]};
                         hb[1] = (u32x4){hi[0], hi[1], hi[0], hi[1]};
                         hb[2] = (u32x4){lo[0], lo[1], mid[0], mid[1]};
@@ -1197,7 +1098,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                         for (int r = 0; r < 4; ++r) d0[b][ct][r] = ((m0[ct] >> (4 * cb + r)) & 1u) ? d0[b][ct][r] : 0.f;
                     if constexpr (!MS) {
                         PiecesB<HB> y1[CT];
-                        split_block_valu(s2, b, d0[b], y1);
+                        split_block_single(s2, b, d0[b], y1);
                         write_buf_rb(cb, y1);
                         LSE_X6_SB();
                     }
@@ -1281,10 +1182,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             for (int nb = 0; nb < KB0; ++nb) {
                 const float (&v)[4 * CT] = vin[nb];
                 if constexpr (CT == 2) {
-                    split_pair<MS>((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4 * CT - 4], v[4 * CT - 3], v[4 * CT - 2], v[4 * CT - 1]}, nI, ib[nb]);
+                    split_pair((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4 * CT - 4], v[4 * CT - 3], v[4 * CT - 2], v[4 * CT - 1]}, nI, ib[nb]);
                 } else {
                     uint32_t hi[2], mid[2], lo[2];
-                    split_half<true>((f32x4){v[0], v[1], v[2], v[3]}, nI, hi, mid, lo);
+                    split_half((f32x4){v[0], v[1], v[2], v[3]}, nI, hi, mid, lo);
                     ib[nb][0] = (u32x4){hi[0], hi[1], mid[0], mid[1]};
                     ib[nb][1] = (u32x4){hi[0], hi[1], hi[0], hi[1]};
                     ib[nb][2] = (u32x4){lo[0], lo[1], mid[0], mid[1]};
