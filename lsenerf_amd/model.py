@@ -116,7 +116,67 @@ class Powpow(nn.Module):
         return x ** self.pow_coeff
 
 
-MAPPERS_DICT = {"gt": GT_Mapper, "identity": IdentityMapper, "powpow": Powpow}   # R:lse_nerf/intensity_mappers.py:89-94
+class _SmallMLP(nn.Module):
+    """nerfstudio ``MLP(in_dim, num_layers=4, layer_width=16, out_dim, ReLU, out_activation=Sigmoid, implementation="torch")``
+    as the mappers of R:lse_nerf/intensity_mappers.py:30-62 build it: four ``nn.Linear`` layers (with bias), parameters named
+    ``layers.{i}.weight / bias`` like nerfstudio's torch MLP so that a reference checkpoint loads."""
+
+    def __init__(self, in_dim: int, out_dim: int, width: int = 16, num_layers: int = 4) -> None:
+        super().__init__()
+        dims = [in_dim] + [width] * (num_layers - 1) + [out_dim]
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            x = torch.relu(x) if i + 1 < len(self.layers) else torch.sigmoid(x)
+        return x
+
+
+def identity_init(mlp: nn.Module, in_dim: int = 3, out_dim: int = 3, n_steps: int = 5000) -> nn.Module:
+    """R:lse_nerf/intensity_mappers.py:8-26: fit the mapper to the identity on 100 grey levels of [0, 1] (Adam, lr 5e-2, MSE)
+    so that training starts from "no tone mapping".  Runs on the module's current device (the reference moves it to the GPU
+    and back; it is 100 x 16 numbers)."""
+    dev = next(mlp.parameters()).device
+    lin = torch.linspace(0, 1, 100, device=dev)[..., None]
+    inp, out_gt = torch.cat([lin] * in_dim, dim=-1), torch.cat([lin] * out_dim, dim=-1)
+    opt = torch.optim.Adam(mlp.parameters(), lr=5e-2)
+    with torch.enable_grad():
+        for _ in range(n_steps):
+            loss = F.mse_loss(mlp(inp), out_gt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    return mlp
+
+
+class MLP_Mapper(nn.Module):
+    """R:lse_nerf/intensity_mappers.py:28-44 (one channel, e.g. behind ``ev_one_dim``)."""
+    init_steps = 5000
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.mlp = identity_init(_SmallMLP(1, 1), 1, 1, self.init_steps)
+
+    def forward(self, x, **kwargs):
+        return self.mlp(x)
+
+
+class RGB_MLP_Mapper(nn.Module):
+    """R:lse_nerf/intensity_mappers.py:47-63 (three channels)."""
+    init_steps = 5000
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.mlp = identity_init(_SmallMLP(3, 3), 3, 3, self.init_steps)
+
+    def forward(self, x, **kwargs):
+        return self.mlp(x)
+
+
+# R:lse_nerf/intensity_mappers.py:93-97.  The MLP mappers act on per-ray values (O(R)); the fused loss epilogue covers the
+# closed-form ones and hands configurations with an MLP mapper to the torch routing (``_epilogue_desc`` returns None).
+MAPPERS_DICT = {"mlp": MLP_Mapper, "rgb_mlp": RGB_MLP_Mapper, "gt": GT_Mapper, "identity": IdentityMapper, "powpow": Powpow}
 format_linear = lambda x: torch.concatenate([x] * 3, dim=-1) if x.shape[-1] == 1 else x
 
 

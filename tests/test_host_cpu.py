@@ -132,6 +132,34 @@ def test_model_wiring_and_param_groups():
     assert not any(k.startswith("hash_table") for k in names)  # the reference's dead 67 MB table is not allocated
 
 
+def test_mlp_intensity_mappers_are_identity_initialised(monkeypatch):
+    """R:lse_nerf/intensity_mappers.py:8-63, 93-97: "mlp" (1 -> 16 -> 16 -> 16 -> 1) and "rgb_mlp" (3 -> ... -> 3), ReLU hidden
+    layers, sigmoid output, fitted to the identity on [0, 1] at construction; selectable through mapping_method /
+    evs_mapping_method like the closed-form mappers, routed by the torch path (the fused epilogue declines them)."""
+    import lsenerf_amd as la
+    from lsenerf_amd import model as M
+    assert set(M.MAPPERS_DICT) == {"mlp", "rgb_mlp", "gt", "identity", "powpow"}
+    torch.manual_seed(0)
+    monkeypatch.setattr(M.MLP_Mapper, "init_steps", 1500)
+    monkeypatch.setattr(M.RGB_MLP_Mapper, "init_steps", 1500)
+    for cls, dim in ((M.MLP_Mapper, 1), (M.RGB_MLP_Mapper, 3)):
+        mp = cls()
+        assert {n for n, _ in mp.named_parameters()} == {f"mlp.layers.{i}.{k}" for i in range(4) for k in ("weight", "bias")}
+        assert mp.mlp.layers[0].weight.shape == (16, dim) and mp.mlp.layers[3].weight.shape == (dim, 16)
+        x = torch.linspace(0.05, 0.95, 37)[:, None].repeat(1, dim)
+        assert float((mp(x) - x).detach().abs().max()) < 0.05                     # identity on the grey axis after the fit
+    m = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="rgb_mlp", map_mode="co_map", evs_mapping_method="mlp",
+                                              ev_one_dim="True"), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4)
+    assert isinstance(m.rgb_mapper, M.RGB_MLP_Mapper) and isinstance(m.evs_mapper, M.MLP_Mapper)
+    n_map = sum(p.numel() for p in m.rgb_mapper.parameters()) + sum(p.numel() for p in m.evs_mapper.parameters())
+    assert n_map == (3 * 16 + 16 + 2 * (16 * 16 + 16) + 16 * 3 + 3) + (1 * 16 + 16 + 2 * (16 * 16 + 16) + 16 + 1)
+    assert sum(p.numel() for p in m.get_param_groups()["fields"]) >= n_map        # trained with the field (R:lsenerf.py:237-243)
+    assert m._epilogue_desc() is None                                              # -> torch routing
+    m.train()
+    routed = m.route_outputs({"rgb": torch.rand(5, 3)}, None, ev_out=True)
+    assert routed["rgb"].shape == (5, 3) and routed["ev_out"].shape == (5, 1)
+
+
 def test_flat_params_and_adam_schedule_cpu():
     from lsenerf_amd.optim import FlatAdam, FlatParams
     a, b = torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(70))
