@@ -182,6 +182,10 @@ def context_default_config(device, steps=20, warmup=6):
                         "grid, SURVEY-8d rays, grid refresh every 16 steps inside the timing", "rays": R, "steps": steps,
             "ms_per_step": ms, "rays_per_s": R / (ms * 1e-3), "occupied_fraction": occ,
             "candidate_samples_per_ray": cand / R, "samples_per_ray_after_culling": kept / R,
+            # per-sample cost of the scatter in THIS regime (survivors spread over the uncontracted interior with growing steps:
+            # ~2x the distinct table lines per sample of M-march), for comparison with the headline's
+            # roofline.kernel_ms / samples_per_step
+            "hash_bwd_ns_per_sample": kern.get("lse_hash_bwd", 0.0) * 1e6 / max(kept, 1),
             "kernel_ms_per_step": kern, "launches_per_step": launches}
 
 
