@@ -252,6 +252,11 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
         // Code size matters here: one wave per SIMD walks this loop nest, so it must stay resident in the instruction
         // cache -- the batch lives in LDS (per-lane slots) + a 16-bit occupancy mask, and every phase is a small
         // dynamic loop with ONE copy of the marching code.
+        // the linear cell index is carried along (one add per step instead of two multiply-adds), and only the axis that was
+        // stepped can leave the grid (the start cell is clamped into it): integer bookkeeping only, the float operations and
+        // their order are the published ones
+        int cell = (cur[0] * a.ry + cur[1]) * a.rz + cur[2] + level * cells_per_level;
+        const int cstep[3] = {stp[0] * a.ry * a.rz, stp[1] * a.rz, stp[2]};
         bool seg_alive = true;
         while (seg_alive && budget > 0) {
             int nb = 0;
@@ -259,21 +264,23 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 float t_traverse = fminf(tdist[0], fminf(tdist[1], tdist[2]));
                 t_traverse = fminf(t_traverse, this_tmax);
                 s_tt[b] = t_traverse;          // every lane writes the same (uniform) value
-                s_cell[b] = (cur[0] * a.ry + cur[1]) * a.rz + cur[2] + level * cells_per_level;
+                s_cell[b] = cell;
                 nb = b + 1;
-                // step to the neighbour cell (ties: x only if strictly smallest, then y, else z)
+                // step to the neighbour cell (ties: x only if strictly smallest, then y, else z).
+                // Leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read); this
+                // implementation stops at the border (DESIGN.md "deviations").
                 bool alive = true;
                 if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
-                    cur[0] += stp[0]; tdist[0] += delta[0]; alive = cur[0] != ovf[0];
+                    cur[0] += stp[0]; tdist[0] += delta[0]; cell += cstep[0];
+                    alive = cur[0] != ovf[0] && (unsigned)cur[0] < (unsigned)a.rx;
                 } else if (tdist[1] < tdist[2]) {
-                    cur[1] += stp[1]; tdist[1] += delta[1]; alive = cur[1] != ovf[1];
+                    cur[1] += stp[1]; tdist[1] += delta[1]; cell += cstep[1];
+                    alive = cur[1] != ovf[1] && (unsigned)cur[1] < (unsigned)a.ry;
                 } else {
-                    cur[2] += stp[2]; tdist[2] += delta[2]; alive = cur[2] != ovf[2];
+                    cur[2] += stp[2]; tdist[2] += delta[2]; cell += cstep[2];
+                    alive = cur[2] != ovf[2] && (unsigned)cur[2] < (unsigned)a.rz;
                 }
-                // leaving the grid without meeting the overflow index is undefined upstream (out-of-bounds read);
-                // this implementation stops at the border (DESIGN.md "deviations").
-                if (!alive || cur[0] < 0 || cur[0] >= a.rx || cur[1] < 0 || cur[1] >= a.ry || cur[2] < 0 || cur[2] >= a.rz)
-                    seg_alive = false;
+                if (!alive) seg_alive = false;
                 --budget;
             }
             // lane b fetches the occupancy byte of look-ahead cell b: one load instruction for the whole batch
