@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 for (int b = 0; b < nb; ++b) {   // one interval per occupied cell
                     const float t_traverse = s_tt[b];
                     if ((occ_mask >> b) & 1u) {
-                        if (WRITE && lane == 0 && n_samples < cap32) {
+                        if (WRITE && n_samples < cap32) {      // (wave-uniform value and address)
                             if (MODE == 1) out_ri[n_samples] = tid;
                             out_ts[n_samples] = t_last;
                             out_te[n_samples] = t_traverse;
@@ -324,7 +324,9 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                             const float dt = calc_dt_t<CONST_DT>(t_last, a.cone_angle, a.step_size, 1e10f);
                             if (t_last + dt * 0.5f >= t_traverse) break;
                             const float t_next = t_last + dt;
-                            if (WRITE && lane == 0 && n_samples < cap32) {
+                            // every lane stores the same (wave-uniform) value to the same address: one request, and no
+                            // exec-mask juggling for "lane 0 only" inside the serial loop
+                            if (WRITE && n_samples < cap32) {
                                 if (MODE == 1) out_ri[n_samples] = tid;
                                 out_ts[n_samples] = t_last;
                                 out_te[n_samples] = t_next;
