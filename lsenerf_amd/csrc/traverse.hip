@@ -310,8 +310,16 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                 // one-event-per-iteration loop full of selects; the kernel is bound by instruction issue (4 waves share a
                 // SIMD, one lane of 64 does the arithmetic).  Same comparisons and additions in the same order.
                 for (int b = 0; b < nb && budget > 0; ++b) {
-                    const float t_traverse = s_tt[b];
                     const bool occupied = (occ_mask >> b) & 1u;
+                    if (!occupied) {
+                        // A run of unoccupied cells is left where its LAST cell is left: the cell boundaries increase along
+                        // the ray and an unoccupied cell only advances t while t + dt/2 < boundary, so stepping cell by cell
+                        // and stepping against the run's last boundary perform the same additions in the same order.
+                        const uint32_t rest = occ_mask >> b;
+                        const int run = rest ? min((int)__builtin_ctz(rest), nb - b) : nb - b;
+                        b += run - 1;
+                    }
+                    const float t_traverse = s_tt[b];
                     if (CONST_DT && a.vec_march &&
                         march_cell_vec<MODE>(occupied, t_traverse, a.step_size, t_last, n_samples, continuous, budget, lane, tid,
                                              out_ri, out_ts, out_te, cap32)) {
