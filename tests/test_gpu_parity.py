@@ -495,6 +495,52 @@ def test_mlp_third_generation_bf16_pieces(monkeypatch, recompute_all, fwd_impl):
         _lib.set_option("mlp_fwd_impl", old)
 
 
+@pytest.mark.parametrize("head", [True, False])
+def test_bf16_piece_arithmetic_has_the_error_level_of_f32(head):
+    """The claim behind dtype "f32" in bench.py: the third-generation forward (three bf16 pieces per operand, six piece products per
+    multiply, f32 accumulate) is NOT a reduced-precision path.  Both arithmetic routes against a float64 evaluation of the same
+    network on the same inputs: the bf16-piece route must be within f32 rounding (a few 1e-7 of the output scale) and no worse than
+    twice the f32-MFMA route + 1e-7."""
+    import ctypes
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    N, R = 20000, 40
+    if head:
+        meta = ops.MlpMeta(16, 64, 2, _lib.LSE_ACT_SIGMOID, _lib.LSE_IN_ROWMAJOR)
+        params = torch.randn(16 * 64 + 64 * 64 + 16 * 64, generator=g) * 0.2
+        x = torch.randn(N, 16, generator=g)
+        bias = torch.randn(R, 64, generator=g) * 0.3
+        ridx = (torch.arange(N) * R // N).int()
+        h = torch.relu(x.double() @ params[:1024].view(64, 16).double().T + bias.double()[ridx.long()])
+        h = torch.relu(h @ params[1024:5120].view(64, 64).double().T)
+        ref = torch.sigmoid(h @ params[5120:].view(16, 64).double().T)
+        xin = x.cuda()
+    else:
+        meta = ops.MlpMeta(32, 64, 1, _lib.LSE_ACT_NONE, _lib.LSE_IN_LEVELMAJOR)
+        params = torch.randn(32 * 64 + 16 * 64, generator=g) * 0.2
+        x = torch.randn(N, 32, generator=g)
+        bias = ridx = None
+        h = torch.relu(x.double() @ params[:2048].view(64, 32).double().T)
+        ref = h @ params[2048:].view(16, 64).double().T
+        xin = x.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    desc = meta.desc()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    pc, bc, rc = params.cuda(), (bias.cuda() if head else None), (ridx.cuda() if head else None)
+    errs = {}
+    old = _lib.get_option("mlp_fwd_impl")
+    try:
+        for impl in (1, 2):
+            _lib.set_option("mlp_fwd_impl", impl)
+            out = torch.empty(N, 16, device="cuda")
+            _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(pc), P(xin), P(bc), P(rc), P(out), 16, None, 1, None, None, 0.0, N, ops._stream())
+            errs[impl] = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    finally:
+        _lib.set_option("mlp_fwd_impl", old)
+    assert errs[1] < 1e-6 and errs[2] < 1e-6, errs
+    assert errs[2] <= 2 * errs[1] + 1e-7, errs
+
+
 @pytest.mark.parametrize("pattern", ["short", "mixed", "tile_aligned", "long"])
 def test_mlp_head_view_bias_column_row_patterns(pattern):
     """The head as the field calls it (first-layer view: leading dimension 64, column offset 15, column 0 masked, compact 4-column
