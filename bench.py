@@ -155,7 +155,7 @@ def context_default_config(device, steps=20, warmup=6):
                    camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device),
                    metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(device)})
     target = torch.rand(R, 3, generator=g).to(device)
-    refresh = model.get_training_callbacks()[0]
+    refresh = model.update_occupancy_grid
     for s in range(0, 64, 16):
         refresh(s)
     occ = float(model.occupancy_grid.binaries.float().mean())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSE_ABI_VERSION 2
+#define LSE_ABI_VERSION 3
 
 #define LSE_OK 0
 #define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
@@ -167,20 +167,26 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
  *                     levels batched into one cache pass (default); 1 = one cache pass per level; 0 = 16-lanes-per-sample kernel
  *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 16)
- *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2, default) =
+ *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2) =
  *                     512 sector slots PAIRED by 64-B line, flushed in slot order -- a float-atomic request costs the same for 4 .. 64
  *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request; 5 = the same with
- *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size)
+ *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size);
+ *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
+ *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 4)
  *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)
+ *   coarse_levels the levels below this one are processed first by a cache-free kernel at high occupancy (lane = sample, run
+ *                     ends transposed through a 1.5 KB staging area, 16 lanes per run add straight to memory); every value is
+ *                     correct, the split only moves time between the two kernels
  *   dbg           timing experiments only (bit 0: skip flush atomics, bit 1: skip run ends, bit 2: skip the scan) -> WRONG results
  * lse_hash_bwd / lse_hash_bwd_levels use lse_hash_bwd_default_opts(). */
 typedef struct lse_hash_bwd_opts {
     int32_t impl, gran, few_runs, second_probe, rounds, dbg;
     float interleave_from_scale;
     int32_t stage_max;
+    int32_t coarse_levels;
 } lse_hash_bwd_opts;
 void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
 int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,

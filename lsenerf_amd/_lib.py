@@ -16,7 +16,7 @@ LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
 LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
 LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
-LSE_ABI_VERSION = 2
+LSE_ABI_VERSION = 3
 
 
 class GridDesc(Structure):
@@ -26,7 +26,7 @@ class GridDesc(Structure):
 
 class HashBwdOpts(Structure):
     _fields_ = [("impl", c_int32), ("gran", c_int32), ("few_runs", c_int32), ("second_probe", c_int32), ("rounds", c_int32),
-                ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32)]
+                ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32), ("coarse_levels", c_int32)]
 
 
 class EpilogueDesc(Structure):

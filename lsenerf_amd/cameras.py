@@ -69,9 +69,11 @@ def exp_map_SE3(tangent_vector: Tensor) -> Tensor:
     scipy.linalg.expm of the 4x4 twist in tests/test_cameras_cpu.py."""
     v, w = tangent_vector[:, :3], tangent_vector[:, 3:]
     t2 = (w * w).sum(-1)
-    t = t2.sqrt()
-    small = t < 1e-2
-    ts = torch.where(small, torch.ones_like(t), t)            # safe denominators
+    small = t2 < 1e-4
+    # the sqrt only ever sees a safe argument: d sqrt / d t2 is infinite at 0, and autograd multiplies that infinity by the
+    # zero the `where` hands back (-> NaN) -- exactly at the zeros CameraOptimizer(mode="SE3") starts from.  Every term
+    # that reaches autograd on the small branch is a polynomial in t2 (nerfstudio's linalg.norm has subgradient 0 there).
+    ts = torch.where(small, torch.ones_like(t2), t2).sqrt()   # safe denominators
     a = torch.where(small, 1 - t2 / 6, ts.sin() / ts)                          # sin t / t
     b = torch.where(small, 0.5 - t2 / 24, (1 - ts.cos()) / (ts * ts))          # (1 - cos t) / t^2
     c = torch.where(small, 1.0 / 6 - t2 / 120, (ts - ts.sin()) / (ts * ts * ts))   # (t - sin t) / t^3

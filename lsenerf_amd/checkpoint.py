@@ -74,6 +74,61 @@ def convert_pipeline_state(pipeline_state: Dict[str, torch.Tensor]) -> Tuple[Dic
     return out, dropped
 
 
+# buffers of the reference's model (they sit between the parameters in the pipeline state dict but are no optimizer entries)
+_REF_BUFFER_LEAVES = ("aabb", "max_res", "num_levels", "log2_hashmap_size", "c2g_vec")
+# get_param_groups order of the reference (R:lse_nerf/lsenerf.py:231-249): field parameters, then the mapper modules
+_REF_GROUP_PREFIXES = ("field.", "rgb_mapper.", "rgb_to_one.", "evs_mapper.")
+# nn.Sequential alias of (mlp_base_grid, mlp_base_mlp) (R:lse_nerf/lse_field.py:208): same tensors again, no new parameters
+_REF_ALIAS_PREFIXES = ("field.mlp_base.",)
+
+
+def reference_param_order(pipeline_state: Dict[str, torch.Tensor]) -> list:
+    """The reference's ``get_param_groups()["fields"]`` as a list of pipeline keys (``_model.`` / ``module.`` prefixes
+    stripped), reconstructed from the checkpoint itself: ``list(self.field.parameters())`` follows the module registration
+    order, which is the key order of the saved state dict, followed by ``rgb_mapper`` / ``rgb_to_one`` / ``evs_mapper``
+    parameters.  Buffers and the ``mlp_base`` Sequential aliases are skipped; the dead hash table and zero-sized tcnn
+    parameters (tcnn's SH encoding) stay in the list -- they consume an index in torch's optimizer state."""
+    keys = []
+    for k in pipeline_state:
+        if k.startswith("module."):
+            k = k[len("module."):]
+        if k.startswith("_model."):
+            keys.append(k[len("_model."):])
+    order = []
+    for prefix in _REF_GROUP_PREFIXES:
+        for k in keys:
+            if not k.startswith(prefix) or k.startswith(_REF_ALIAS_PREFIXES) or k.rsplit(".", 1)[-1] in _REF_BUFFER_LEAVES:
+                continue
+            order.append(k)
+    return order
+
+
+def reference_optimizer_index_map(pipeline_state: Dict[str, torch.Tensor], model: torch.nn.Module, params: list):
+    """({reference optimizer index: position in ``params`` or None}, {reference index: key}) for the "fields" group.
+    ``params`` is the local optimizer's parameter list (``FlatParams.params``); a reference parameter maps to the local
+    parameter of the same (translated) name, to None when this model has no such tensor (dead table, zero-sized tcnn
+    parameters).  Raises when a non-empty, non-dead reference parameter has no local counterpart."""
+    local_by_name = dict(model.named_parameters())
+    pos = {id(p): i for i, p in enumerate(params)}
+    index_map, names = {}, {}
+    stripped = {}
+    for k, v in pipeline_state.items():
+        kk = k[len("module."):] if k.startswith("module.") else k
+        if kk.startswith("_model."):
+            stripped[kk[len("_model."):]] = v
+    for i, k in enumerate(reference_param_order(pipeline_state)):
+        names[i] = k
+        lk = reference_to_local_key("_model." + k)
+        p = local_by_name.get(lk) if lk is not None else None
+        if p is not None and id(p) in pos:
+            index_map[i] = pos[id(p)]
+        elif lk is None or stripped[k].numel() == 0:
+            index_map[i] = None
+        else:
+            raise ValueError(f"reference parameter {k!r} (optimizer index {i}) has no counterpart in the local parameter list")
+    return index_map, names
+
+
 def load_nerfstudio_checkpoint(path: str, model: torch.nn.Module, load_step: Optional[int] = None,
                                drop_camera_optimizer: bool = False,
                                optimizers: Optional[Dict[str, object]] = None) -> Dict[str, object]:
@@ -108,7 +163,14 @@ def load_nerfstudio_checkpoint(path: str, model: torch.nn.Module, load_step: Opt
     if optimizers:   # resume: Adam moments + step count (the lr schedule continues from there)
         for name, o in optimizers.items():
             if name in loaded.get("optimizers", {}):
-                o.load_state_dict(loaded["optimizers"][name])
+                sd = loaded["optimizers"][name]
+                flat = getattr(o, "flat", None)
+                if name == "fields" and flat is not None and not sd.get("lsenerf_amd_layout", False):
+                    # reference-written state: indices follow the reference's parameter list, translate them by name
+                    imap, names = reference_optimizer_index_map(loaded["pipeline"], model, flat.params)
+                    o.load_state_dict(sd, index_map=imap, names=names)
+                else:
+                    o.load_state_dict(sd)
     return {"step": int(loaded["step"]), "missing": list(res.missing_keys), "unexpected": list(res.unexpected_keys),
             "dropped": list(dropped)}
 

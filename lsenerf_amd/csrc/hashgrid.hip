@@ -69,6 +69,34 @@ __device__ __forceinline__ uint32_t grid_index(const LevelInfo &li, uint32_t px,
     return idx;
 }
 
+// The 8 corner indices of the cell (p0, p1, p2) at once.  Same values as grid_index() per corner (all arithmetic is mod 2^32:
+// (p + 1) * prime == p * prime + prime), but the two quarter-rate 32-bit multiplies of the hash are issued once per sample
+// instead of once per corner, and a dense level costs one multiply-add pair plus wave-uniform offsets (the per-corner form
+// compiles to 16 v_mul_lo_u32 / v_mad_u64_u32 per sample and level, each a 16-cycle instruction on CDNA).
+__device__ __forceinline__ void corner_indices(const LevelInfo &li, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t (&idx)[8])
+{
+    if (li.dense) {
+        const uint32_t r2 = li.res * li.res;                       // (scalar)
+        const uint32_t b = p0 + p1 * li.res + p2 * r2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t i = b + ((c & 1) ? 1u : 0u) + ((c & 2) ? li.res : 0u) + ((c & 4) ? r2 : 0u);
+            if (i >= li.size) i -= li.size;                        // == i % size for inputs in [0,1] (see grid_index)
+            if (i >= li.size) i %= li.size;
+            idx[c] = i;
+        }
+    } else {
+        const uint32_t hy0 = p1 * kPrimeY, hz0 = p2 * kPrimeZ;
+        const uint32_t hy1 = hy0 + kPrimeY, hz1 = hz0 + kPrimeZ;
+        const uint32_t h[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t i = (p0 + (c & 1)) ^ h[c >> 1];
+            idx[c] = li.pow2 ? (i & (li.size - 1)) : (i % li.size);
+        }
+    }
+}
+
 __device__ __forceinline__ void pos_fract(float x, float scale, float &w, uint32_t &p)
 {
     const float pos = fmaf(scale, x, 0.5f);
@@ -135,11 +163,10 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
     float2 v[kFwdItems][8];
 #pragma unroll
     for (int it = 0; it < kFwdItems; ++it) {
+        uint32_t idx[8];
+        corner_indices(li, p[it][0], p[it][1], p[it][2], idx);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t idx = grid_index(li, p[it][0] + (c & 1), p[it][1] + ((c >> 1) & 1), p[it][2] + ((c >> 2) & 1));
-            v[it][c] = tab[idx];
-        }
+        for (int c = 0; c < 8; ++c) v[it][c] = tab[idx[c]];
     }
 #pragma unroll
     for (int it = 0; it < kFwdItems; ++it) {
@@ -335,6 +362,11 @@ __device__ __forceinline__ int row_shr_i32(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true);
 }
 
+// Whole-wave shifts by one lane as DPP moves (GFX9 wave_shr / wave_shl): `__shfl_up(v, 1)` compiles to ds_bpermute_b32, an LDS
+// instruction, and the hash backward is bound by the LDS pipe.  Lane 0 (63) receives its own value; callers test the lane.
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }
+
 // lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2])
 __device__ __forceinline__ int quad_swap1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
 
@@ -443,8 +475,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
             float2 gy = dy[(int64_t)l * n + si[r]];
             if (!valid[r]) gy = make_float2(0.f, 0.f);
             uint32_t idx[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) idx[c] = grid_index(li, p0 + (c & 1), p1 + ((c >> 1) & 1), p2 + ((c >> 2) & 1));
+            corner_indices(li, p0, p1, p2, idx);
             float2 tv[8];
             if (WITH_DX) {
 #pragma unroll
@@ -671,7 +702,14 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // odd sector) and builds the flush list by scanning the keys in slot order, so sibling sectors sit in neighbouring 8-lane groups
 // of one flush instruction and go out as ONE contiguous 64-byte request; the scan also replaces the per-corner list appends of
 // the insert path (fewer instructions per pass).
-template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false>
+// kFlush2 (round 3): the kernel is bound by the CU's LDS pipe -- every DS wave-instruction costs 7 .. 8 cycles of it
+// (13 / 22 for the 32- / 64-bit compare-and-swap; profiles/r02_micro_lds_ops.txt), a cache pass issued ~190 of them, 140 of
+// those in the flush (per 32 slots: 4 list reads, 4 key reads, 4 payload reads, 4 payload resets, 4 key resets), and
+// 256 waves x ~9 passes x 1500 cycles per CU is the 1.5 ms the ablation attributes to the cache passes.  Flush with fewer DS
+// instructions: the list is stored trip-major transposed, so the 4 slots a lane group handles in a trip are one 8-byte read;
+// the payload is read AND zeroed by one ds_wrxchg_rtn_b32; the keys are reset in bulk after the last trip (2 x ds_write_b128
+// per lane).  Per 32 slots: 1 + 4 + 4 = 9 instead of 20 DS instructions, per pass ~75 instead of ~140 in the flush.
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -843,7 +881,12 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 for (int s0 = 0; s0 < kSlots; s0 += 64) {
                     const bool occ = key[s0 + lane] != kNoLine;
                     const uint64_t om = __builtin_amdgcn_ballot_w64(occ);
-                    if (occ) list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0))] = (uint16_t)(s0 + lane);
+                    if (occ) {
+                        uint32_t pos = used + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
+                        // trip-major transposed: list position i of trip i / 32 is handled by lane group i % 8 as its (i % 32) / 8-th slot
+                        if constexpr (kFlush2) pos = (pos & ~31u) + ((pos & 7u) << 2) + ((pos >> 3) & 3u);
+                        list[pos] = (uint16_t)(s0 + lane);
+                    }
                     used += __builtin_popcountll(om);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -851,6 +894,41 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             }
             constexpr int kPer = 64 / kPay;   // slots per flush instruction
             const int sub = lane & (kPay - 1);
+            if constexpr (kFlush2) {
+                static_assert(!kFlush2 || (kPair && kPay == 8 && kSlots == 512), "flush v2: 512 paired 32-byte slots");
+                const uint32_t gq = (uint32_t)lane >> 3;
+                for (uint32_t t0 = 0; t0 < used; t0 += 32) {
+                    const uint64_t four = *(lds_u64 *)&list[t0 + 4 * gq];
+                    uint32_t sl[4], ln[4];
+                    float vv[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ok[u] = t0 + 8 * u + gq < used;
+                        sl[u] = ok[u] ? (uint32_t)(four >> (16 * u)) & 0xFFFFu : (uint32_t)lane;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ln[u] = key[sl[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)       // read + zero in one DS instruction; idle lanes swap their private dummy word
+                        vv[u] = __hip_atomic_exchange(ok[u] ? &val[sl[u] * kPay + sub] : (lds_f32 *)dummy32, 0.f, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u] && vv[u] != 0.f && !(dbg & 1)) atomicAdd(dtable + (size_t)ln[u] * kPay + sub, vv[u]);
+                }
+                if (used) {      // every occupied key was in the list: reset all of them, 8 keys per lane
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
+                    lds_u32x4 *k4 = (lds_u32x4 *)key;
+                    const u32x4_t none = {kNoLine, kNoLine, kNoLine, kNoLine};
+                    k4[lane] = none;
+                    k4[64 + lane] = none;
+                    *dummy32 = kNoLine;      // (the exchange above left 0.f in the idle lanes' dummy word)
+                }
+            } else
             for (uint32_t e0 = lane / kPay; e0 < used; e0 += 4 * kPer) {
                 uint32_t ent[4], ln[4];
                 float vv[4];
@@ -890,17 +968,16 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             float2 gy = dy[(int64_t)l * n + si[r]];
             if (!valid[r]) gy = make_float2(0.f, 0.f);
             uint32_t idx[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) idx[c] = grid_index(li, p0 + (c & 1), p1 + ((c >> 1) & 1), p2 + ((c >> 2) & 1));
+            corner_indices(li, p0, p1, p2, idx);
             float2 tv[8];
             if (WITH_DX) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
             }
             // runs of lanes in the same cell
-            const uint32_t q0 = __shfl_up(p0, 1), q1 = __shfl_up(p1, 1), q2 = __shfl_up(p2, 1);
+            const uint32_t q0 = wave_shr1(p0), q1 = wave_shr1(p1), q2 = wave_shr1(p2);
             const int head = (lane == 0) || (q0 != p0) || (q1 != p1) || (q2 != p2);
-            const int next_head = __shfl_down(head, 1);
+            const int next_head = wave_shl1(head);
             const bool run_end = (lane == 63) || next_head;
             float v[16];
 #pragma unroll
@@ -927,14 +1004,17 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 seg_scan_cross_rows(v, open, lane);
             }
             if (WITH_DX) {
+                // d(x): t_c = <dy, table[c]>; along each axis the difference of the two faces, weighted by the other two axes
+                const float a0 = 1.f - w0, a1 = 1.f - w1, a2 = 1.f - w2;
+                float t[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float sx = (c & 1) ? w0 : 1.f - w0, sy = (c & 2) ? w1 : 1.f - w1, sz = (c & 4) ? w2 : 1.f - w2;
-                    const float t = li.scale * (gy.x * tv[c].x + gy.y * tv[c].y);
-                    dacc[r][0] += t * ((c & 1) ? 1.f : -1.f) * (sy * sz);
-                    dacc[r][1] += t * ((c & 2) ? 1.f : -1.f) * (sx * sz);
-                    dacc[r][2] += t * ((c & 4) ? 1.f : -1.f) * (sx * sy);
-                }
+                for (int c = 0; c < 8; ++c) t[c] = gy.x * tv[c].x + gy.y * tv[c].y;
+                const float d0 = a2 * (a1 * (t[1] - t[0]) + w1 * (t[3] - t[2])) + w2 * (a1 * (t[5] - t[4]) + w1 * (t[7] - t[6]));
+                const float d1 = a2 * (a0 * (t[2] - t[0]) + w0 * (t[3] - t[1])) + w2 * (a0 * (t[6] - t[4]) + w0 * (t[7] - t[5]));
+                const float d2 = a1 * (a0 * (t[4] - t[0]) + w0 * (t[5] - t[1])) + w1 * (a0 * (t[6] - t[2]) + w0 * (t[7] - t[3]));
+                dacc[r][0] = fmaf(li.scale, d0, dacc[r][0]);
+                dacc[r][1] = fmaf(li.scale, d1, dacc[r][1]);
+                dacc[r][2] = fmaf(li.scale, d2, dacc[r][2]);
             }
             // ---- run ends add their 8 corner sums into the line cache, then the level's lines are flushed.
             // The kernel is instruction-issue bound (rocprof: VALU+SALU+LDS issue ~ 3 ms of a 3.6 ms launch), so this part
@@ -1027,6 +1107,128 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 }
 
 
+// Coarse levels (round 3).  Inside the fused launch above, every level below ~9 costs 0.09 ms although a wave ends only 1 .. 10
+// runs there and sends 0.1 .. 0.4 lines per sample to memory (gpurun_out/r3a): those levels pay for the fine levels'
+// machinery -- the 80 KB of LDS per workgroup that hold the sector cache cap the kernel at two waves per SIMD, and at that
+// occupancy nothing hides the latency of the eight table gathers, the dy load and the scan's DPP chain of a level.  This
+// kernel has no cache: lane = sample, the same segmented scan leaves each run's 8 x 2 corner sums in the run's last lane, the
+// run ends are transposed through a 1.5 KB per-wave staging area (16 runs per trip) and added to memory with 16 lanes per run
+// (lane = corner x feature: the two features and the x / x+1 neighbours of an entry share one request).  6 KB of LDS per
+// workgroup and < 128 registers: the occupancy is set by the registers, and the waves of a SIMD hide each other's latencies.
+// Any level is handled correctly (a fine level just sends more requests than the cache would), so the split level is a
+// tuning parameter of the launch (lse_hash_bwd_opts.coarse_levels), not a correctness condition.
+template <bool WITH_DX>
+__global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, const float *__restrict__ x,
+                                                              const float2 *__restrict__ dy,
+                                                              const float2 *__restrict__ table,
+                                                              float *__restrict__ dtable, float *__restrict__ dx,
+                                                              int64_t n, int dbg)
+{
+    constexpr int kBatch = 16;                      // run ends per staging trip
+    __shared__ uint32_t s_stage[4][kBatch * 24];    // [run][8 idx | 16 sums]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (wave_base >= n) return;                     // (no workgroup barrier anywhere below)
+    lds_u32 *stage = (lds_u32 *)&s_stage[wave][0];
+    const int64_t i0 = wave_base + lane;
+    const bool valid = i0 < n;
+    const int64_t si = valid ? i0 : n - 1;
+    const float px0 = x[si * 3 + 0], px1 = x[si * 3 + 1], px2 = x[si * 3 + 2];
+    float dacc0 = 0.f, dacc1 = 0.f, dacc2 = 0.f;
+    const int k16 = lane & 15, sub_run = lane >> 4;
+
+    for (int l = g.l_begin; l < g.l_end; ++l) {
+        const LevelInfo li = level_info(g, l);
+        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;
+        const float2 *__restrict__ tab = table + li.offset;
+        float w0, w1, w2;
+        uint32_t p0, p1, p2;
+        pos_fract(px0, li.scale, w0, p0);
+        pos_fract(px1, li.scale, w1, p1);
+        pos_fract(px2, li.scale, w2, p2);
+        float2 gy = dy[(int64_t)l * n + si];
+        if (!valid) gy = make_float2(0.f, 0.f);
+        uint32_t idx[8];
+        corner_indices(li, p0, p1, p2, idx);
+        float2 tv[8];
+        if (WITH_DX && !(dbg & 8)) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
+        }
+        const uint32_t q0 = wave_shr1(p0), q1 = wave_shr1(p1), q2 = wave_shr1(p2);
+        const int head = (lane == 0) || (q0 != p0) || (q1 != p1) || (q2 != p2);
+        const int next_head = wave_shl1(head);
+        const bool run_end = ((lane == 63) || next_head) && !(dbg & 2);
+        float v[16];
+        const float a0 = 1.f - w0, a1 = 1.f - w1, a2 = 1.f - w2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float wt = ((c & 1) ? w0 : a0) * ((c & 2) ? w1 : a1) * ((c & 4) ? w2 : a2);
+            v[2 * c] = wt * gy.x;
+            v[2 * c + 1] = wt * gy.y;
+        }
+        if (!(dbg & 4)) {
+            const int row_pos = lane & 15;
+            int flag = head | (row_pos == 0);
+            if (seg_scan_row_step<1>(v, flag, row_pos) && seg_scan_row_step<2>(v, flag, row_pos) &&
+                seg_scan_row_step<4>(v, flag, row_pos))
+                seg_scan_row_step<8>(v, flag, row_pos);
+            int open = !head;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const int o = (off == 1) ? row_shr_i32<1>(open) : (off == 2) ? row_shr_i32<2>(open)
+                            : (off == 4) ? row_shr_i32<4>(open) : row_shr_i32<8>(open);
+                open &= (row_pos >= off) ? o : 1;
+            }
+            seg_scan_cross_rows(v, open, lane);
+        }
+        if (WITH_DX && !(dbg & 8)) {
+            // d(x): t_c = <dy, table[c]>; along each axis the difference of the two faces, weighted by the other two axes
+            float t[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) t[c] = gy.x * tv[c].x + gy.y * tv[c].y;
+            const float d0 = a2 * (a1 * (t[1] - t[0]) + w1 * (t[3] - t[2])) + w2 * (a1 * (t[5] - t[4]) + w1 * (t[7] - t[6]));
+            const float d1 = a2 * (a0 * (t[2] - t[0]) + w0 * (t[3] - t[1])) + w2 * (a0 * (t[6] - t[4]) + w0 * (t[7] - t[5]));
+            const float d2 = a1 * (a0 * (t[4] - t[0]) + w0 * (t[5] - t[1])) + w1 * (a0 * (t[6] - t[2]) + w0 * (t[7] - t[3]));
+            dacc0 = fmaf(li.scale, d0, dacc0);
+            dacc1 = fmaf(li.scale, d1, dacc1);
+            dacc2 = fmaf(li.scale, d2, dacc2);
+        }
+        const uint64_t ends_mask = __builtin_amdgcn_ballot_w64(run_end);
+        const int n_ends = __builtin_popcountll(ends_mask);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0));
+        for (int b0 = 0; b0 < n_ends; b0 += kBatch) {
+            const int r = rank - b0;
+            if (run_end && r >= 0 && r < kBatch) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) stage[r * 24 + c] = idx[c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) stage[r * 24 + 8 + k] = __float_as_uint(v[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = min(kBatch, n_ends - b0);
+            for (int r0 = sub_run; r0 < cnt; r0 += 4) {
+                const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
+                const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
+                if (a != 0.f && !(dbg & 1)) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();      // the next trip (or level) overwrites the staging area
+        }
+    }
+    if (WITH_DX && valid) {
+        if (g.dx_accumulate) {
+            dacc0 += dx[si * 3 + 0];
+            dacc1 += dx[si * 3 + 1];
+            dacc2 += dx[si * 3 + 2];
+        }
+        dx[si * 3 + 0] = dacc0;
+        dx[si * 3 + 1] = dacc1;
+        dx[si * 3 + 2] = dacc2;
+    }
+}
+
 int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
 {
     LSE_REQUIRE(desc, "%s: null desc", who);
@@ -1072,13 +1274,15 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     if (!o) return;
     o->impl = 2;           // lane-per-sample + LDS sector cache, run ends of several levels batched per cache pass
     o->stage_max = 16;     // impl 2: a level ending more runs than this per wave passes unstaged when the queue is empty
-    o->gran = 4;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line (2 = unpaired); impl 1: 2 / 3
+    o->gran = 6;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line, second-generation flush (4 = first-generation
+                           // flush, 2 = unpaired); impl 1: 2 / 3
     o->few_runs = 4;       // tuned on MI355X: 4..8 equal, 16 already slower
     o->second_probe = 1;   // extra probe rounds (next slot) before a corner goes to memory alone; pays wherever the kernel is
                            // bound by atomic requests (sphere rays 4.27 -> 3.86 ms), costs ~2 % where it is issue-bound
     o->rounds = 32;
     o->dbg = 0;
     o->interleave_from_scale = 1e30f;   // measured negative on MI355X (same-address lanes of one atomic instruction serialise)
+    o->coarse_levels = 0;  // levels below this one run in the cache-free high-occupancy kernel (hash_bwd_coarse_kernel) first
 }
 
 extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
@@ -1103,7 +1307,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     if (opts) o = *opts;
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 5, "lse_hash_bwd: opts.gran must be 2 .. 5");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 6, "lse_hash_bwd: opts.gran must be 2 .. 6");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1119,10 +1323,30 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(x01 && dy && dtable, "lse_hash_bwd: null pointer");
     LSE_REQUIRE(!dx || table, "lse_hash_bwd: dx requested but table is null");
+    LSE_REQUIRE(o.coarse_levels >= 0 && o.coarse_levels <= LSE_MAX_GRID_LEVELS, "lse_hash_bwd: opts.coarse_levels out of range");
     const float il_scale = o.interleave_from_scale;
     const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
+    // the coarse share of the level range first, in the cache-free kernel; the rest of the range then accumulates into dx
+    const int coarse_end = std::min<int>(o.coarse_levels, level_end);
+    if (coarse_end > level_begin) {
+        GridParams gc = g;
+        gc.l_end = coarse_end;
+        const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
+        LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
+        const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
+        const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        if (dx) hipLaunchKernelGGL((hash_bwd_coarse_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
+                                   dx, n, dbg);
+        else hipLaunchKernelGGL((hash_bwd_coarse_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
+                                dx, n, dbg);
+        rc = lse::check_launch("lse_hash_bwd (coarse levels)");
+        if (rc) return rc;
+        if (coarse_end == level_end) return LSE_OK;
+        g.l_begin = coarse_end;
+        g.dx_accumulate = 1;
+    }
     // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
     bool lines_ok = true;
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
@@ -1135,6 +1359,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            return lse::check_launch("lse_hash_bwd");
+        }
+        if (o.gran == 6) {      // gran 4 with the second-generation flush (fewer DS instructions per cache pass)
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
             return lse::check_launch("lse_hash_bwd");
         }

@@ -197,7 +197,12 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
         // formed as exp(-sum -log(1 - alpha_i)) with the same scan, the alpha threshold is tested on the input value itself
         const float sd = from_alpha ? -log1pf(-fminf(sg, 1.f)) : sg * (b - a);
         const float incl = lse::wave_inclusive_sum(sd);
-        const float T = expf(-((incl - sd) + carry));
+        // exclusive prefix = the inclusive one shifted by a lane, not `incl - sd`: a fully opaque sample (alpha == 1.0f, which
+        // sigma * dt > ~17 rounds to) has sd = +inf, and inf - inf = NaN would cull the sample although its own transmittance
+        // prod_{i<k} (1 - alpha_i) is finite (nerfacc's exclusive product keeps it); everything behind it gets T = 0
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0.f;
+        const float T = expf(-(excl + carry));
         const float alpha = from_alpha ? sg : 1.f - expf(-sd);
         bool vis = valid && (T >= eps);
         if (alpha_thre > 0.f) vis = vis && (alpha >= alpha_thre);

@@ -48,11 +48,14 @@ class LSENeRFModelConfig:
     emb_norm_weight: float = 1e-2
     event_loss_type: str = "log_loss"
     use_mapping: bool = False
-    mapping_method: str = "identity"
-    evs_mapping_method: Optional[str] = None
+    mapping_method: str = "mlp"                      # (only read when use_mapping is on; the presets pass it explicitly)
+    evs_mapping_method: Optional[str] = "None"
     ev_one_dim: object = "learned"
     rgb_loss_type: str = "linspace"
-    map_mode: str = "evs_rgb"
+    use_mapper_loss: bool = False                    # carried for call compatibility: nothing in the reference reads these three
+    mapper_loss_weight: float = 0.25
+    scaler_weight: float = 1.0
+    map_mode: str = "ev_rgb"                         # the reference's default spelling; routing only looks at it with use_mapping
     embed_config: LSEEmbeddingConfig = field(default_factory=LSEEmbeddingConfig)
     # --- field size knobs (BASELINE config 1 uses L=4, 2x32)
     num_levels: int = 16
@@ -71,6 +74,48 @@ class LSENeRFModelConfig:
                 self.ev_one_dim = "learned"
         if self.rgb_loss_type.lower() == "none":
             self.rgb_loss_type = "linspace"
+
+
+class GbConfig:
+    """R:lse_nerf/utils.py:14-19: process-wide run flags the reference flips from its eval scripts."""
+    DO_PRETRAIN = False
+    IS_EVAL = False
+    IS_RENDER = False
+
+
+gbconfig = GbConfig()
+
+
+class _TrainingCallbackLocation:
+    """nerfstudio.engine.callbacks.TrainingCallbackLocation (stand-in used only where nerfstudio is not installed)."""
+    BEFORE_TRAIN_ITERATION = "before_train_iteration"
+    AFTER_TRAIN_ITERATION = "after_train_iteration"
+    AFTER_TRAIN = "after_train"
+
+
+class _TrainingCallback:
+    """nerfstudio.engine.callbacks.TrainingCallback stand-in: same constructor, attributes and run methods."""
+
+    def __init__(self, where_to_run, func, update_every_num_iters=None, iters=None, args=None, kwargs=None):
+        assert "step" in func.__code__.co_varnames if hasattr(func, "__code__") else True
+        self.where_to_run, self.func = where_to_run, func
+        self.update_every_num_iters, self.iters = update_every_num_iters, iters
+        self.args, self.kwargs = (args if args is not None else []), (kwargs if kwargs is not None else {})
+
+    def run_callback(self, step: int) -> None:
+        if self.update_every_num_iters is not None:
+            if step % self.update_every_num_iters == 0:
+                self.func(*self.args, **self.kwargs, step=step)
+        elif self.iters is not None:
+            if step in self.iters:
+                self.func(*self.args, **self.kwargs, step=step)
+
+    def run_callback_at_location(self, step: int, location) -> None:
+        if location in self.where_to_run:
+            self.run_callback(step=step)
+
+    def __call__(self, step: int) -> None:
+        self.run_callback(step)
 
 
 class ThreeToOne(nn.Module):
@@ -259,6 +304,9 @@ class LSENeRFModel(nn.Module):
         """``scene_box``: a nerfstudio-style ``SceneBox`` (anything with ``.aabb`` [2,3]) as nerfstudio's
         ``Model.__init__(config, scene_box, num_train_data, **kwargs)`` receives it, or the aabb tensor itself."""
         super().__init__()
+        if not isinstance(config, LSENeRFModelConfig):      # nerfstudio hands over ITS config object (ns_plugin entry point)
+            from .ns_plugin import convert_model_config
+            config = convert_model_config(config)
         self.config = config
         self.scene_box = scene_box if hasattr(scene_box, "aabb") else SceneBox(aabb=scene_box.float().reshape(2, 3))
         self.scene_aabb_2x3 = self.scene_box.aabb.float().reshape(2, 3)
@@ -305,15 +353,28 @@ class LSENeRFModel(nn.Module):
         elif cfg.ev_one_dim == "gt":
             self.rgb_to_one = ToGrayGT()
 
-    def get_training_callbacks(self):
-        """NGPModel.get_training_callbacks: occupancy refresh before every train iteration."""
-        def update_occupancy_grid(step: int):
-            self.occupancy_grid.update_every_n_steps(
-                step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
-        return [update_occupancy_grid]
+    def update_occupancy_grid(self, step: int) -> None:
+        """The body of NGPModel's training callback: refresh the occupancy grid from ``density * render_step_size``."""
+        self.occupancy_grid.update_every_n_steps(
+            step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[object]:
+        """nerfstudio 0.3.2 ``NGPModel.get_training_callbacks(training_callback_attributes)`` (inherited by the reference,
+        R:lse_nerf/lsenerf.py:141): one callback, before every train iteration, that refreshes the occupancy grid.  With
+        nerfstudio importable this is its ``TrainingCallback(where_to_run=[BEFORE_TRAIN_ITERATION], update_every_num_iters=1,
+        func=...)`` object, which the Trainer drives through ``run_callback_at_location``; without nerfstudio (this image) a
+        ``TrainingCallback`` stand-in with the same attributes and ``run_callback`` / ``run_callback_at_location`` methods,
+        which is also directly callable with the step."""
+        try:
+            from nerfstudio.engine.callbacks import TrainingCallback, TrainingCallbackLocation
+        except ModuleNotFoundError:
+            TrainingCallback, TrainingCallbackLocation = _TrainingCallback, _TrainingCallbackLocation
+        return [TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], update_every_num_iters=1,
+                                 func=self.update_occupancy_grid)]
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
-        """R:lse_nerf/lsenerf.py:231-249 (NGPModel: {"fields": field parameters})."""
+        """R:lse_nerf/lsenerf.py:231-249 (NGPModel: {"fields": field parameters}).  In an evaluation run (``gbconfig.IS_EVAL``,
+        :246-247) only the appearance embedding is optimised: the radiance field is frozen and the test-time embedding fitted."""
         groups = {"fields": list(self.field.parameters())}
         if self.config.mapping_method == "gt":
             return groups
@@ -323,7 +384,32 @@ class LSENeRFModel(nn.Module):
             groups["fields"] += list(self.rgb_to_one.parameters())
         if self.config.evs_mapping_method is not None and self.evs_mapper is not None:
             groups["fields"] += list(self.evs_mapper.parameters())
+        if gbconfig.IS_EVAL:
+            groups["fields"] = list(self.field.embedding_appearance.parameters())
         return groups
+
+    def init_test_params(self):   # R:lse_nerf/lsenerf.py:251-252
+        self.field.embedding_appearance.init_test_params()
+
+    # -- metrics (R:lse_nerf/lsenerf.py:378-388 over nerfstudio 0.3.2 NGPModel.get_metrics_dict) ------------------
+    @staticmethod
+    def psnr(preds: Tensor, target: Tensor) -> Tensor:
+        """torchmetrics ``PeakSignalNoiseRatio(data_range=1.0)`` as NGPModel holds it: 10 log10(1 / mse)."""
+        return 10.0 * torch.log10(1.0 / F.mse_loss(preds, target))
+
+    def _ngp_metrics_dict(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        image = batch["image"].to(outputs["rgb"].device)
+        return {"psnr": self.psnr(outputs["rgb"], image), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, object]:
+        """{"psnr", "num_samples_per_batch"} for a plain rgb batch; for the multi-bundle step {"col": that dict of the colour
+        bundle} (nothing is logged for the event bundles)."""
+        if outputs.get("col_out") is None and outputs.get("prev_out") is None:
+            return self._ngp_metrics_dict(outputs, batch)
+        metrics = {}
+        if outputs["col_out"] is not None:
+            metrics["col"] = self._ngp_metrics_dict(outputs["col_out"], batch["col_batch"])
+        return metrics
 
     def correct_evs_dim(self, inp):
         return self.rgb_to_one(inp) if self.config.ev_one_dim else inp

@@ -89,22 +89,49 @@ class FlatAdam:
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(self.flat.params))),
                  "initial_lr": self.lr_init, "lr_final": self.lr_final, "max_steps": self.max_steps}
-        return {"state": state, "param_groups": [group]}
+        # (the marker tells checkpoint.load_nerfstudio_checkpoint that the indices are positions in THIS parameter list)
+        return {"state": state, "param_groups": [group], "lsenerf_amd_layout": True}
 
-    def load_state_dict(self, sd: dict) -> None:
+    def load_state_dict(self, sd: dict, index_map: Optional[dict] = None, names: Optional[dict] = None) -> None:
+        """Load a torch.optim.Adam-style state dict.
+
+        Without ``index_map`` the state indices are positions in THIS optimizer's parameter list -- i.e. a state dict written by
+        ``state_dict()`` above (or by ``torch.optim.Adam`` over the same list).  A state dict written by the REFERENCE indexes
+        its own parameter list, which contains parameters this model does not have (the dead torch-layout hash table,
+        R:lse_nerf/lse_field.py:63-65) and orders the rest by its own module registration order; pass
+        ``index_map = {reference index: local index or None}`` (``checkpoint.reference_optimizer_index_map`` builds it from
+        the checkpoint's pipeline keys; ``load_nerfstudio_checkpoint`` does so) and ``names`` (reference index -> key, for the
+        error messages).  A state entry that maps to no local parameter and is not known to be dead, or whose shape differs
+        from the parameter it maps to, raises: moments are never matched by position alone across the two layouts."""
         state = sd["state"]
-        assert len(state) in (0, len(self.flat.params)), "optimizer state does not match the parameter list"
-        steps = set()
-        for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
-            st = state.get(i, state.get(str(i)))
-            if st is None:
+        n_local = len(self.flat.params)
+        names = names or {}
+        if index_map is None:
+            if len(state) not in (0, n_local) or (state and {int(k) for k in state} != set(range(n_local))):
+                raise ValueError(f"optimizer state has {len(state)} entries for {n_local} parameters: not a state dict of this "
+                                 "parameter list (for a reference-written checkpoint pass index_map, see the docstring)")
+            index_map = {i: i for i in range(n_local)}
+        steps, seen = set(), set()
+        for key, st in state.items():
+            ri = int(key)
+            if ri not in index_map:
+                raise ValueError(f"optimizer state index {ri} ({names.get(ri, '?')}) is not covered by the index map")
+            li = index_map[ri]
+            if li is None:      # a parameter this model does not hold (dead table / zero-sized tcnn parameter)
                 continue
+            if li in seen:
+                raise ValueError(f"two optimizer states map to local parameter {li} ({names.get(ri, '?')})")
+            seen.add(li)
+            p, o = self.flat.params[li], self.flat.offsets[li]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape) and st["exp_avg"].numel() != p.numel():
+                raise ValueError(f"optimizer state {ri} ({names.get(ri, '?')}): shape {tuple(st['exp_avg'].shape)} does not fit "
+                                 f"local parameter {li} of shape {tuple(p.shape)}")
             n = p.numel()
-            assert tuple(st["exp_avg"].shape) == tuple(p.shape), f"state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}"
             self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
-        assert len(steps) <= 1, f"parameters disagree on the step count: {steps}"
+        if len(steps) > 1:
+            raise ValueError(f"parameters disagree on the step count: {sorted(steps)}")
         if steps:
             self.step_count = steps.pop()
         g = sd["param_groups"][0]

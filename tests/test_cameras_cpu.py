@@ -191,6 +191,41 @@ def test_se3_exponential_matches_scipy_expm_and_drives_the_optimizer():
     assert float(opt.pose_adjustment.grad[2, 3:].abs().sum()) > 0
 
 
+def test_se3_exponential_has_finite_exact_gradients_at_the_zero_tangent():
+    """CameraOptimizer(mode="SE3") starts from pose_adjustment = 0: the gradient there must be finite and equal the analytic
+    Jacobian of exp at the identity -- d[R | t]/d(v, omega) = [omega^ generators | I for v, 0.5 * omega^ v terms] -- and the
+    value/gradient must be continuous across the Taylor switch at |omega| = 1e-2."""
+    p = torch.zeros(2, 6, dtype=torch.float64, requires_grad=True)
+    m = cam.exp_map_SE3(p)
+    assert torch.equal(m[0].detach(), torch.eye(3, 4, dtype=torch.float64))
+    # d(sum of c_ij * M_ij) for a fixed random c: analytic at identity: dM/dv_k = e_k in the last column; dM/dw_k = hat(e_k) in R
+    c = torch.tensor(np.random.default_rng(5).normal(size=(3, 4)))
+    (m[0] * c).sum().backward()
+    g = p.grad[0]
+    assert torch.isfinite(p.grad).all()
+    hat = lambda k: np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]]) if k == 0 else (
+        np.array([[0, 0, 1], [0, 0, 0], [-1, 0, 0]]) if k == 1 else np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0]]))
+    want = [float(c[k, 3]) for k in range(3)] + [float((c[:, :3].numpy() * hat(k)).sum()) for k in range(3)]
+    assert np.abs(g.numpy() - np.array(want)).max() < 1e-12
+    # float32 as the optimiser holds it, through CameraOptimizer: one Adam step from zeros stays finite
+    opt = cam.CameraOptimizerConfig(mode="SE3").setup(num_cameras=2, device="cpu")
+    from lsenerf_amd import RayBundle
+    rb = RayBundle(torch.zeros(2, 3), torch.tensor([[1.0, 0, 0], [0, 1.0, 0]]), camera_indices=torch.tensor([[0], [1]]))
+    opt.apply_to_raybundle(rb)
+    (rb.origins.sum() + (rb.directions * torch.tensor([0.3, -0.2, 0.5])).sum()).backward()
+    assert torch.isfinite(opt.pose_adjustment.grad).all() and float(opt.pose_adjustment.grad[:, 3:].abs().sum()) > 0
+    # continuity across the branch switch
+    for scale in (0.999e-2, 1.001e-2):
+        q = (torch.tensor([[0.2, -0.1, 0.3, 0.6, -0.64, 0.48]], dtype=torch.float64) * torch.tensor([1, 1, 1, scale, scale, scale])
+             ).requires_grad_(True)
+        mm = cam.exp_map_SE3(q)
+        (mm[0] * c).sum().backward()
+        if scale < 1e-2:
+            lo_v, lo_g = mm.detach().clone(), q.grad.clone()
+        else:
+            assert (mm.detach() - lo_v).abs().max() < 1e-4 and (q.grad - lo_g).abs().max() < 1e-4
+
+
 def test_prev_next_optimizer_alternates_and_prefixes():
     """R:lse_nerf/ns_camera_optimizer.py:368-414."""
     from lsenerf_amd import RayBundle

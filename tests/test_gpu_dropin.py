@@ -293,3 +293,35 @@ def test_sampler_with_a_foreign_density_fn_and_alpha_fn():
     assert abs(ts_s.shape[0] - ts_al.shape[0]) <= max(2, ts_s.shape[0] // 2000)
     if ts_s.shape[0] == ts_al.shape[0]:
         assert torch.equal(ri_s, ri_al) and torch.equal(ts_s, ts_al)
+
+
+def test_visibility_from_alpha_keeps_a_fully_opaque_sample():
+    """nerfacc.render_visibility_from_alpha (R:lse_nerf/lse_grid_estimator.py:133): T_k = prod_{i<k} (1 - alpha_i), exclusive.
+    alpha == 1.0f (what sigma * dt > ~17 rounds to) in the middle of a ray: that sample itself is still visible (its own
+    transmittance is finite), everything behind it is culled; a ray that starts with alpha == 1 keeps exactly its first sample.
+    Checked against a float64 exclusive cumprod (ragged rays, one spanning several 64-sample chunks)."""
+    from lsenerf_amd import nerfacc_compat as nc
+    g = torch.Generator().manual_seed(4)
+    cnts = [5, 0, 200, 1, 70]
+    alphas, want = [], []
+    for r, c in enumerate(cnts):
+        a = (torch.rand(c, generator=g) * 0.02).float()
+        if r == 0:
+            a[2] = 1.0
+        if r == 2:
+            a[130] = 1.0
+        if r == 4:
+            a[0] = 1.0
+        T = torch.cat([torch.ones(1, dtype=torch.float64), torch.cumprod(1.0 - a.double(), 0)[:-1]]) if c else torch.zeros(0, dtype=torch.float64)
+        alphas.append(a)
+        want.append((T >= 1e-4) & (a >= 0.005).to(torch.bool))
+    al = torch.cat(alphas).cuda()
+    cnt = torch.tensor(cnts, dtype=torch.long)
+    packed = torch.stack([torch.cumsum(cnt, 0) - cnt, cnt], -1).cuda().contiguous()
+    got = nc.render_visibility_from_alpha(al, packed_info=packed, early_stop_eps=1e-4, alpha_thre=0.005).cpu()
+    want = torch.cat(want)
+    assert got.dtype == torch.bool and torch.equal(got, want)
+    off = [0, 5, 5, 205, 206]
+    assert bool(got[off[0] + 2]) and not got[off[0] + 3:off[0] + 5].any()       # the opaque sample survives, the rest does not
+    assert bool(got[off[2] + 130]) and not got[off[2] + 131:off[2] + 200].any()
+    assert bool(got[off[4]]) and not got[off[4] + 1:].any()

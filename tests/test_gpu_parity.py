@@ -287,7 +287,14 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
     variants = {"default": {}, "unpaired_sectors": {"gran": 2}, "paired_probe2": {"gran": 4, "second_probe": 2}, "stage_all": {"stage_max": 64}, "stage_none": {"stage_max": 0}, "batched_probe0": {"second_probe": 0}, "batched_probe3": {"second_probe": 3},
                 "batched_no_few_runs": {"few_runs": 0}, "per_level_pass": {"impl": 1}, "line_cache": {"impl": 1, "gran": 3},
                 "second_probe": {"impl": 1, "second_probe": 1}, "no_few_runs": {"impl": 1, "few_runs": 0},
-                "lanes16": {"impl": 0}, "lanes16_r64": {"impl": 0, "rounds": 64}}
+                "lanes16": {"impl": 0}, "lanes16_r64": {"impl": 0, "rounds": 64},
+                # round 3: the cache-free high-occupancy kernel takes the levels below `coarse_levels` (a split of the level
+                # range between two launches; all of them = that kernel alone, incl. its multi-trip staging on the fine levels)
+                "coarse6": {"coarse_levels": 6}, "coarse9": {"coarse_levels": 9}, "coarse_all": {"coarse_levels": 16},
+                "coarse8_impl1": {"coarse_levels": 8, "impl": 1}, "coarse5_lanes16": {"coarse_levels": 5, "impl": 0},
+                # second-generation flush of the paired sector cache (transposed list, read-and-zero exchange, bulk key reset)
+                "flush2": {"gran": 6}, "flush2_coarse7": {"gran": 6, "coarse_levels": 7}, "flush2_stage_all": {"gran": 6, "stage_max": 64},
+                "flush2_no_few_runs": {"gran": 6, "few_runs": 0, "second_probe": 0}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
     for sc in meta.scales:

@@ -26,14 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
     assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts"} == set(names)
-    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 2
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 3
 
 
 def test_runtime_options_and_hash_bwd_opts_without_gpu():
     """Tuning knobs are call arguments (lse_hash_bwd_ex) or run-time options -- no process-lifetime environment statics."""
     from lsenerf_amd import _lib
     o = _lib.hash_bwd_default_opts()
-    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max) == (2, 4, 4, 1, 32, 0, 16)
+    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 4, 1, 32, 0, 16, 0)
     assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28
     _lib.set_option("mlp_fwd_cfg", 44)
     assert _lib.get_option("mlp_fwd_cfg") == 44
@@ -199,3 +199,56 @@ def test_embedding_modes_and_errors():
     est.eval()
     with pytest.raises(RuntimeError):
         est.update_every_n_steps(0, lambda x: x)
+
+
+def test_outer_boundary_with_the_references_keyword_set():
+    """The nerfstudio-facing surface with the reference's own keywords (no nerfstudio needed): the model accepts a config object
+    that is NOT lsenerf_amd's dataclass -- what ``ns-train`` hands over -- and converts it field by field
+    (R:lse_nerf/lsenerf.py:47-99); ``get_training_callbacks(training_callback_attributes)`` returns TrainingCallback objects bound
+    to BEFORE_TRAIN_ITERATION (NGPModel); ``get_metrics_dict`` (R:lse_nerf/lsenerf.py:378-388) and the IS_EVAL parameter group
+    (:246-247) exist."""
+    import types
+    import lsenerf_amd as la
+    from lsenerf_amd import model as M, ns_plugin
+    # every keyword of the reference's LSENeRFModelConfig with the reference's defaults + the InstantNGP fields it inherits
+    ref_kw = dict(evs_loss_weight=1.0, emb_norm_weight=1e-2, event_loss_type="log_loss", use_mapping=False, mapping_method="mlp",
+                  evs_mapping_method="None", ev_one_dim="learned", rgb_loss_type="linspace", use_mapper_loss=False,
+                  mapper_loss_weight=0.25, scaler_weight=1.0, map_mode="ev_rgb", eval_num_rays_per_chunk=3512,
+                  grid_resolution=128, grid_levels=4, max_res=2048, log2_hashmap_size=19, alpha_thre=0.01, cone_angle=0.004,
+                  render_step_size=None, near_plane=0.05, far_plane=1e3, background_color="random", disable_scene_contraction=False)
+    assert la.LSENeRFModelConfig(**ref_kw) == la.LSENeRFModelConfig()          # same names, same defaults
+    foreign_embed = types.SimpleNamespace(embedding_type="evs_emb", metadata="dummy", emb_dim=32, eval_mode="mean", extra=1)
+    foreign = types.SimpleNamespace(_target=object, collider_params=None, loss_coefficients={}, embed_config=foreign_embed,
+                                    **{**ref_kw, "evs_mapping_method": None, "evs_loss_weight": 0.5, "grid_levels": 2,
+                                       "grid_resolution": 16})
+    cfg = ns_plugin.convert_model_config(foreign)
+    assert isinstance(cfg, la.LSENeRFModelConfig) and cfg.evs_loss_weight == 0.5 and cfg.grid_levels == 2
+    assert isinstance(cfg.embed_config, la.LSEEmbeddingConfig) and cfg.embed_config.embedding_type == "evs_emb" \
+        and cfg.embed_config.eval_mode == "mean"
+    m = la.LSENeRFModel(foreign, la.SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=12)
+    assert isinstance(m.config, la.LSENeRFModelConfig) and m.occupancy_grid.binaries.shape == (2, 16, 16, 16)
+    assert type(m.field.embedding_appearance).__name__ == "EvsFrameEmbedding"
+    # training callbacks: nerfstudio's signature and object shape
+    (cb,) = m.get_training_callbacks(training_callback_attributes=object())
+    assert cb.update_every_num_iters == 1 and len(cb.where_to_run) == 1 and "BEFORE_TRAIN_ITERATION" in str(cb.where_to_run[0]).upper()
+    assert cb.func == m.update_occupancy_grid and hasattr(cb, "run_callback_at_location")
+    (cb0,) = m.get_training_callbacks()
+    assert type(cb0) is type(cb)
+    # metrics
+    out = {"rgb": torch.full((5, 3), 0.5), "num_samples_per_ray": torch.tensor([3, 0, 2, 1, 4])}
+    md = m.get_metrics_dict(out, {"image": torch.full((5, 3), 0.6)})
+    assert abs(float(md["psnr"]) - 20.0) < 1e-4 and int(md["num_samples_per_batch"]) == 10
+    md2 = m.get_metrics_dict({"col_out": out, "prev_out": None, "next_out": None}, {"col_batch": {"image": torch.full((5, 3), 0.6)}})
+    assert set(md2) == {"col"} and abs(float(md2["col"]["psnr"]) - 20.0) < 1e-4
+    assert m.get_metrics_dict({"col_out": None, "prev_out": out, "next_out": out}, {}) == {}
+    # evaluation run: only the appearance embedding is optimised
+    n_all = len(m.get_param_groups()["fields"])
+    M.gbconfig.IS_EVAL = True
+    try:
+        ev = m.get_param_groups()["fields"]
+        assert n_all > 1 and len(ev) == 1 and ev[0] is m.field.embedding_appearance.embedding.weight
+    finally:
+        M.gbconfig.IS_EVAL = False
+    # the plugin entry point still fails with the explanatory message where nerfstudio is absent
+    with pytest.raises(ModuleNotFoundError, match="nerfstudio==0.3.2"):
+        ns_plugin.build_method_specification()

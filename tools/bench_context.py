@@ -50,7 +50,7 @@ def main():
                    camera_indices=torch.zeros(R, 1, dtype=torch.long, device=dev),
                    metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(dev)})
     target = torch.rand(R, 3, generator=g).to(dev)
-    cb = model.get_training_callbacks()[0]
+    cb = model.update_occupancy_grid
     for step in range(0, 64, 16):                                # carve the grid with the reference's update rule
         cb(step)
     occ_frac = float(model.occupancy_grid.binaries.float().mean())

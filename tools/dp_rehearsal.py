@@ -93,7 +93,7 @@ def run(mode: str, rank: int, world: int, dev, batch):
     rb = RayBundle(origins=batch["o"][sl].clone().requires_grad_(True), directions=batch["d"][sl].clone().requires_grad_(True),
                    camera_indices=torch.zeros(sl.stop - sl.start, 1, dtype=torch.long, device=dev),
                    metadata={"appearance_id": batch["aid"][sl]})
-    refresh = model.get_training_callbacks()[0]
+    refresh = model.update_occupancy_grid
     grids_ok = []
     pre_sync = []
     if not single:     # rank 0's grid after every refresh; what the ranks computed on their own is recorded first

@@ -41,7 +41,7 @@ def positions_default_config():
     gg = torch.Generator().manual_seed(7)
     o, d = bench.sphere_rays(R, gg)
     rb = RayBundle(origins=o.to(dev), directions=d.to(dev), camera_indices=torch.zeros(R, 1, dtype=torch.long, device=dev))
-    cb = model.get_training_callbacks()[0]
+    cb = model.update_occupancy_grid
     for s in range(0, 64, 16):
         cb(s)
     rs, _ = model.sampler(ray_bundle=rb, near_plane=0.05, far_plane=1e3, render_step_size=model.config.render_step_size,

@@ -33,7 +33,7 @@ def default_config_positions():
         model.field.mlp_base_mlp.params[-16 * 64:-15 * 64].mul_(6.0)
     o, d = bench.sphere_rays(R, torch.Generator().manual_seed(7))
     rb = RayBundle(origins=o.to(dev), directions=d.to(dev), camera_indices=torch.zeros(R, 1, dtype=torch.long, device=dev))
-    cb = model.get_training_callbacks()[0]
+    cb = model.update_occupancy_grid
     for s_ in range(0, 64, 16):
         cb(s_)
     rs, _ = model.sampler(ray_bundle=rb, near_plane=0.05, far_plane=1e3, render_step_size=model.config.render_step_size,
@@ -49,16 +49,21 @@ for name, x01 in regimes.items():
     fns = []
     for v in variants:
         o = _lib.hash_bwd_default_opts()
+        nodx = False
         for kv in v.split():
             k, val = kv.split("=")
-            setattr(o, k, int(val))
-        fns.append((v, o))
+            if k == "nodx":
+                nodx = bool(int(val))
+            else:
+                setattr(o, k, int(val))
+        fns.append((v, (o, nodx)))
     times = {v: [] for v, _ in fns}
     for rnd in range(6):
-        for v, o in fns:
+        for v, (o, nodx) in fns:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, ctypes.byref(o), ops._stream())
+            _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), None if nodx else P(dx), 0, 0, 16, n,
+                      ctypes.byref(o), ops._stream())
             e1.record(); torch.cuda.synchronize()
             if rnd: times[v].append(e0.elapsed_time(e1))
     for v, _ in fns:
