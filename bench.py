@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the LSENeRF hot path on MI355X: train-step rays/sec on a 4096-ray x 1024-sample batch
-(BASELINE.json metric; SURVEY.md section 8d workload "M-march").
+(BASELINE.json metric; SURVEY.md section 8d workload "M-march", taken literally since round 3).
 
-One step = occupancy-grid ray marching (4-level 128^3 grid, fully occupied = the training regime of steps < 256,
-constant step, per-ray t_max capped so that every ray yields exactly 1024 samples) -> hash-grid field + fused MLPs
-forward -> packed volume rendering -> MSE(rgb, target) -> backward (incl. ray/pose gradients) -> [RCCL all-reduce of
-the flat gradient] -> fused Adam.  Synthetic rays, random-init parameters, fp32 throughout.
+One step = occupancy-grid ray marching (ONE-level 128^3 grid, all cells occupied, cone angle 0, no culling;
+rays from the sphere of radius 1.5 aimed at uniform targets in [-0.5, 0.5]^3; constant step chosen so that the rays
+yield 1024 samples on average -- the actual N is reported) -> hash-grid field + fused MLPs forward -> packed volume
+rendering -> MSE(rgb, target) -> backward (incl. ray/pose gradients) -> [RCCL all-reduce of the flat gradient] -> fused
+Adam.  Synthetic rays, random-init parameters, fp32 throughout.  Extra keys of the JSON line (N = 1 only): the round-1/2
+headline workload (`m_march_inside_box`: origins inside the box, exactly 1024 samples per ray -- the friendlier input),
+SURVEY 8d's M-packed, the reference's default configuration, and the reference's real 3-bundle step compositions.
 
     python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); per-GPU work is fixed (weak
@@ -39,25 +42,41 @@ MLP_BF16_FLOP_PER_SAMPLE = (180 + 96 + 528 + 244) * 16384 // 32
 HBM_PEAK = 8.0e12                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_workload(device, seed):
+def build_workload(device, seed, kind="sphere"):
+    """kind "sphere": SURVEY 8d M-march exactly (the headline).  kind "inside": the round-1/2 headline (origins in
+    [-0.5, 0.5]^3, 4-level grid, per-ray t_max capped: exactly 1024 samples per ray, 65 % of them in the contracted shell)."""
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
     torch.manual_seed(96)                                     # identical parameters on every rank
-    cfg = LSENeRFModelConfig(cone_angle=0.0, alpha_thre=0.0)  # M-march: constant step, no culling
+    inside = kind == "inside"
+    cfg = LSENeRFModelConfig(cone_angle=0.0, alpha_thre=0.0, grid_levels=4 if inside else 1)   # constant step, no culling
     model = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(device)
     model.train()
     model.occupancy_grid.mark_all_occupied()
     g = torch.Generator().manual_seed(seed)                   # rank-dependent rays (R:train.py:104 seeds by rank)
     R = RAYS_PER_GPU
-    o = (torch.rand(R, 3, generator=g) - 0.5)
-    d = torch.randn(R, 3, generator=g)
-    d = d / d.norm(dim=-1, keepdim=True)
-    step = cfg.render_step_size
-    fars = torch.full((R, 1), cfg.near_plane + SAMPLES_PER_RAY * step - 0.25 * step)
+    if inside:
+        o = (torch.rand(R, 3, generator=g) - 0.5)
+        d = torch.randn(R, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        step = cfg.render_step_size
+        fars = torch.full((R, 1), cfg.near_plane + SAMPLES_PER_RAY * step - 0.25 * step).to(device)
+    else:
+        o, d = sphere_rays(R, g)
+        fars = None
     target = torch.rand(R, 3, generator=g)
-    jitter = torch.zeros(R)                                   # fixed draw: sample count stays exactly 1024 per ray
+    jitter = torch.zeros(R)                                   # fixed draw: the sample count does not change from step to step
     rb = RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
-                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device), fars=fars.to(device),
+                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device), fars=fars,
                    metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(device)})
+    if not inside:
+        # "step chosen so the mean count is ~1024 per ray": the count is ~ (chord inside the box) / step, so one marcher
+        # call at the reference's step and one correction settle it (the same rule on every rank; rays differ by rank)
+        est = model.occupancy_grid
+        for _ in range(3):
+            n = est.sampling(rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                             render_step_size=cfg.render_step_size, stratified=True, jitter=jitter.to(device),
+                             return_packed=True)[1].shape[0]
+            cfg.render_step_size = float(cfg.render_step_size * n / (R * SAMPLES_PER_RAY))
     return model, rb, target.to(device), jitter.to(device)
 
 
@@ -68,7 +87,7 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
     cfg = model.config
     ri, ts, te, packed = model.occupancy_grid.sampling(
         rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
-        t_max=rb.fars.reshape(-1), render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
+        t_max=rb.fars.reshape(-1) if rb.fars is not None else None, render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
         alpha_thre=cfg.alpha_thre, jitter=jitter, return_packed=True)
     # (pipelined exchange: the all-reduce + Adam of the previous step finished inside sampling(), right after the marcher,
     #  through the estimator's after_march_hook -- dist.GradPipeline.attach)
@@ -189,6 +208,26 @@ def context_default_config(device, steps=20, warmup=6):
             "kernel_ms_per_step": kern, "launches_per_step": launches}
 
 
+def context_inside_box(device, steps=12, warmup=4):
+    """The round-1/2 headline workload as context: origins inside the box, 4-level grid, exactly 1024 samples per ray."""
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    model, rb, target, jitter = build_workload(device, seed=1000, kind="inside")
+    flat = FlatParams(model.get_param_groups()["fields"])
+    opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
+    last = {}
+
+    def step(i):
+        last["n"], _ = train_step(model, rb, target, jitter, opt, 1)
+
+    ms, kern, _ = _timed_steps(step, steps, warmup)
+    n = last["n"]
+    return {"workload": "M-march as benchmarked in rounds 1-2: origins in [-0.5,0.5]^3, 4-level 128^3 grid fully occupied, per-ray "
+                        "t_max capped -> exactly 1024 samples per ray (65 % of them in the contracted shell, where consecutive "
+                        "samples share fine cells: the friendlier input)",
+            "samples_per_step": n, "ms_per_step": ms, "rays_per_s": RAYS_PER_GPU / (ms * 1e-3), "kernel_ms_per_step": kern,
+            "hash_bwd_alg_GBps": HASH_BYTES_PER_SAMPLE * n / (kern.get("lse_hash_bwd", 1e9) * 1e-3) / 1e9}
+
+
 def context_m_packed(device, steps=12, warmup=4):
     """SURVEY.md 8d 'M-packed' (kernel roofline inputs): the estimator is bypassed; 4096 rays from the radius-1.5 sphere,
     ray_indices = repeat_interleave(arange(R), 1024), t_starts = 0.05 + k * step, t_ends = t_starts + step."""
@@ -297,6 +336,8 @@ def main():
     mode = os.environ.get("LSE_BENCH_EXCHANGE", "pipelined" if world > 1 else "plain")
     if mode == "sharded":
         sharded = ldist.ShardedAdamExchange(flat, lr=1e-2, eps=1e-15)
+    if world > 1:      # rank 0's grid after every refresh (DDP's buffer broadcast, R:lse_nerf/lse_pipeline.py:97); M-march's grid is
+        ldist.attach_grid_sync(model.occupancy_grid)      # fully occupied and never refreshed, the hook is part of the template
     if mode == "pipelined":
         pipeline = ldist.GradPipeline(opt, world).attach(model.occupancy_grid)
     if mode in ("overlap", "split"):
@@ -345,25 +386,29 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rays_per_s = world * RAYS_PER_GPU / (elapsed / args.steps)
-        assert n_samples == RAYS_PER_GPU * SAMPLES_PER_RAY, f"workload drifted: {n_samples} samples"
+        assert abs(n_samples / (RAYS_PER_GPU * SAMPLES_PER_RAY) - 1.0) < 0.01, f"workload drifted: {n_samples} samples"
         dom = max(("lse_hash_bwd", "lse_hash_fwd"), key=lambda k: dom_ms_all.get(k, 0.0))
         dom_ms = dom_ms_all[dom]
         achieved = HASH_BYTES_PER_SAMPLE * n_samples / (dom_ms * 1e-3) / 1e9
         b_step = n_samples * BYTES_PER_SAMPLE_STEP + 8 * 4 * flat.numel
-        traffic = None
+        traffic, sq_busy = None, None
         try:   # committed PMC summary of the same kernels (bench.py cannot run rocprofv3 on itself); see profiles/pmc_traffic.json
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(dom, {}).get("bytes")
+                pmc = json.load(f)
+            traffic = pmc.get(dom, {}).get("bytes")
+            sq_busy = pmc.get("matrix_core_busy")
         except OSError:
             pass
         line = {
             "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "M-march: LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, SH4, "
-                                   "32-d appearance embedding), 4096 rays/GPU x 1024 samples (4-level 128^3 grid fully "
-                                   "occupied, constant step), fwd+bwd+Adam, grads w.r.t. rays included",
-                       "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": SAMPLES_PER_RAY, "samples_per_step": n_samples,
+            "config": {"workload": "M-march (SURVEY 8d, exact): LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, "
+                                   "SH4, 32-d appearance embedding); 4096 rays/GPU from the radius-1.5 sphere aimed into "
+                                   "[-0.5,0.5]^3, one-level 128^3 occupancy grid fully occupied, cone 0, no culling, constant step "
+                                   "chosen for 1024 samples per ray on average; sampler + fwd + bwd + Adam, grads w.r.t. rays included",
+                       "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": n_samples / RAYS_PER_GPU, "samples_per_step": n_samples,
+                       "render_step_size": model.config.render_step_size,
                        "parallelism": f"dp{world}", "grad_exchange": mode},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
@@ -372,16 +417,15 @@ def main():
                               "achieved_GBps": b_step / (ms_per_step * 1e-3) / 1e9 * 1.0,
                               "frac_of_hbm_peak": b_step / (ms_per_step * 1e-3) / HBM_PEAK},
             "mfma": (lambda t_ms: {
-                "kernels": "lse_mlp_fwd+lse_mlp_bwd+lse_mlp_wgrad", "ms": t_ms,
+                "kernels": "lse_mlp_fwd+lse_mlp_bwd", "ms": t_ms,
                 "note": "f32-equivalent arithmetic on the bf16 matrix cores (three bf16 pieces per operand, six piece products, f32 "
-                        "accumulate): `achieved_TFLOPs` prices the ALGORITHMIC f32 flops (fwd + data grad + weight grad, no "
-                        "recompute) against the f32-MFMA peak the path used in round 1; `executed_bf16_*` prices the MFMA "
-                        "instructions actually issued (piece products, recomputed layers, remainder MFMAs) against the dense bf16 peak",
-                "flop_per_sample": MLP_FLOP_PER_SAMPLE,
-                "achieved_TFLOPs": MLP_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 1e12, "peak_TFLOPs": 157.3,
+                        "accumulate; the backward recomputes the hidden layers): `executed_bf16_*` prices the MFMA instructions "
+                        "actually issued against the dense bf16 peak; `matrix_core_busy` is SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x "
+                        "kernel cycles) from the committed rocprofv3 --pmc summary of the same kernels",
                 "executed_bf16_flop_per_sample": MLP_BF16_FLOP_PER_SAMPLE,
                 "executed_bf16_TFLOPs": MLP_BF16_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 1e12, "bf16_peak_TFLOPs": 2500.0,
-                "executed_bf16_frac": MLP_BF16_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 2.5e15})(
+                "executed_bf16_frac": MLP_BF16_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 2.5e15,
+                "matrix_core_busy": sq_busy})(
                     kern_ms.get("lse_mlp_fwd", 0) + kern_ms.get("lse_mlp_bwd", 0) + kern_ms.get("lse_mlp_wgrad", 0) + 1e-9),
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
             "kernel_ms_note": "per C-ABI entry point, from a separate instrumented pass of %d steps (event pairs around every "
@@ -391,6 +435,8 @@ def main():
         }
         if world == 1 and not args.no_context:
             del model, flat, opt
+            torch.cuda.empty_cache()
+            line["m_march_inside_box"] = context_inside_box(device)
             torch.cuda.empty_cache()
             line["default_config"] = context_default_config(device)
             torch.cuda.empty_cache()

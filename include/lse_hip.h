@@ -206,6 +206,10 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
  *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
  *                       MFMAs; default), 0 = first-generation kernel
  *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
+ *   "traverse_fma"      0 (default) = every product and sum of the traversal set-up rounded separately (bit-exact against
+ *                       oracle/c/liblse_oracle.so); 1 = the a*b+c sites of nerfacc's grid.cu (ray start / end, the two products of
+ *                       tmax_xyz) as fused multiply-adds -- what nvcc's default contraction emits -- bit-exact against
+ *                       liblse_oracle_fma.so.  The two settings differ in about one sample interval per million
  * Returns LSE_E_INVALID for an unknown name.  Integer outputs never depend on these; floating-point results agree within
  * rounding (mlp_fwd_impl chooses between two arithmetic routes of the same accuracy, the rest only reorder launches). */
 int lse_set_option(const char *name, int64_t value);

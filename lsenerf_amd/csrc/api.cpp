@@ -27,6 +27,7 @@ static Option g_options[] = {
     {"mlp_bwd3_cfg", {208}},
     {"mlp_act_nt", {0}},
     {"traverse_vec", {1}},
+    {"traverse_fma", {0}},
 };
 int64_t option(const char *name)
 {

@@ -36,6 +36,8 @@ struct TraverseArgs {
     int64_t cap;          // MODE 2: samples of ray r go to slots [r*cap, (r+1)*cap)
     int32_t *overflow;    // MODE 2: set when a ray produced more than cap samples (never, by the host's bound)
     int vec_march;        // constant step: march 64 steps of a cell at once (march_cell_vec); 0 = published serial loop only
+    int fma_setup;        // option "traverse_fma": the a*b+c sites of the traversal setup as fused multiply-adds (nvcc's default
+                          // contraction of grid.cu); 0 = every product and sum rounded separately (default, == oracle build 1)
 };
 
 __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
@@ -232,12 +234,14 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             const float resf = (float)res[k];
             const float ext = box[3 + k] - box[k];
             const float voxel = ext / resf;
-            const float rs = o[k] + d[k] * (this_tmin + eps);
-            const float re = o[k] + d[k] * (this_tmax - eps);
+            // (this file is compiled with -ffp-contract=off: only the explicit fmaf calls fuse)
+            const float rs = a.fma_setup ? fmaf(d[k], this_tmin + eps, o[k]) : o[k] + d[k] * (this_tmin + eps);
+            const float re = a.fma_setup ? fmaf(d[k], this_tmax - eps, o[k]) : o[k] + d[k] * (this_tmax - eps);
             cur[k] = clampi((int)(((rs - box[k]) / ext) * resf), 0, res[k] - 1);
             const int fin = clampi((int)(((re - box[k]) / ext) * resf), 0, res[k] - 1);
             const int start_index = cur[k] + (d[k] > 0 ? 1 : 0);
-            const float tmax_k = ((box[k] + (((float)start_index * voxel) - rs)) * inv[k]) + this_tmin;
+            const float tmax_k = a.fma_setup ? fmaf(box[k] + fmaf((float)start_index, voxel, -rs), inv[k], this_tmin)
+                                             : ((box[k] + (((float)start_index * voxel) - rs)) * inv[k]) + this_tmin;
             tdist[k] = (d[k] == 0.0f) ? this_tmax : tmax_k;
             const float stepf = (d[k] == 0.0f) ? 0.0f : (d[k] > 0.0f ? 1.0f : -1.0f);
             stp[k] = (int)stepf;
@@ -451,7 +455,7 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
     if (mode == 0) LSE_REQUIRE(chunk_cnts, "lse_traverse_grids: count pass needs chunk_cnts");
     if (mode == 1) LSE_REQUIRE(chunk_starts && ray_indices && t_starts && t_ends, "lse_traverse_grids: write pass needs outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr, vec_march_enabled()};
+                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr, vec_march_enabled(), (int)lse::option("traverse_fma")};
     const int blocks = n_rays;   // one wave per ray
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
@@ -480,7 +484,7 @@ extern "C" int lse_traverse_grids_slots(const float *rays_o, const float *rays_d
     LSE_REQUIRE((int64_t)levels * rx * ry * rz < (1ll << 31), "lse_traverse_grids_slots: grid too large (levels*cells >= 2^31)");
     LSE_REQUIRE(cap >= 1 && chunk_cnts && t_start_slots && t_end_slots && overflow, "lse_traverse_grids_slots: bad outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow, vec_march_enabled()};
+                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow, vec_march_enabled(), (int)lse::option("traverse_fma")};
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
     if (const_dt) hipLaunchKernelGGL((traverse_kernel<2, true>), dim3(n_rays), dim3(64), 0, st, a);

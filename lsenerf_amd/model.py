@@ -543,6 +543,48 @@ class LSENeRFModel(nn.Module):
             losses["event_loss"] = self.config.evs_loss_weight * self.event_loss(evs, prev_in, next_in, batch["evs_batch"])
         return losses
 
+    # -- the reference's training step (R:lse_nerf/lse_pipeline.py:110-145) as ONE packed pass ----------------------------
+    def train_step_bundles(self, col_bundle: Optional[RayBundle], prev_bundle: Optional[RayBundle],
+                           next_bundle: Optional[RayBundle], batch: Dict[str, object], jitter: Optional[Tensor] = None,
+                           with_metrics: bool = False):
+        """``LSENeRFPipeline.get_train_loss_dict`` for bundles the data manager has already produced: returns
+        ``(out_dict, loss_dict, metrics_dict)`` with ``out_dict = {"col_out", "prev_out", "next_out"}``.
+
+        The reference runs up to three model forwards per step -- colour bundle, previous-event bundle, next-event bundle
+        (2316 / 597 / 597 rays at its default batch, R:lse_nerf/lse_datamanager.py:135-144) -- each with its own sampler call,
+        host synchronisations, field pass, renderer and, in backward, its own hash-table scatter.  Rays are independent, so the
+        three bundles are rendered here as ONE packed batch: one marcher launch, one visibility pre-pass, one field pass, one
+        volume-rendering kernel, one loss epilogue, ONE hash backward; per-bundle outputs are row slices of the packed
+        result.  Every ray gets exactly the samples and values it gets in a pass of its own (``jitter``: one stratified
+        offset per ray, colour rays first, for callers that need the draw reproduced); only the order in which gradient
+        contributions are summed differs.  ``with_metrics``: also route the colour render and report NGPModel's psnr /
+        num_samples_per_batch (R:lse_nerf/lsenerf.py:378-388) -- a handful of O(R) torch ops outside the fused epilogue."""
+        assert self.training, "train_step_bundles is the training step; use forward() / get_outputs() for evaluation"
+        names = ("col_out", "prev_out", "next_out")
+        given = [(k, b) for k, b in zip(names, (col_bundle, prev_bundle, next_bundle)) if b is not None and len(b) > 0]
+        assert given, "no rays in this step"
+        if (prev_bundle is not None and len(prev_bundle) > 0) != (next_bundle is not None and len(next_bundle) > 0):
+            raise ValueError("previous and next event bundles come in pairs")
+        rb = RayBundle.cat([b for _, b in given])
+        if self.collider is not None:
+            rb = self.collider(rb)
+        raw = self.exec_get_outputs(rb, jitter=jitter)
+        out_dict: Dict[str, Optional[Dict[str, Tensor]]] = {k: None for k in names}
+        lo = 0
+        for k, b in given:
+            hi = lo + len(b)
+            out_dict[k] = {key: val[lo:hi] for key, val in raw.items()}
+            lo = hi
+        loss_dict = self.fused_loss_dict(out_dict, batch)
+        metrics_dict: Dict[str, object] = {}
+        if with_metrics and out_dict["col_out"] is not None:
+            with torch.no_grad():
+                routed = self.route_outputs({k: v.detach() for k, v in out_dict["col_out"].items()}, col_bundle)
+                md = self.get_metrics_dict({"col_out": routed, "prev_out": out_dict["prev_out"], "next_out": out_dict["next_out"]},
+                                           batch)
+            metrics_dict = {f"{k1}_{k2}": v for k1, d in md.items() for k2, v in d.items()}   # flatten_metrics_dict (:100-107)
+        return out_dict, loss_dict, metrics_dict
+
     # -- fused training epilogue -----------------------------------------------------------------------------
     def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor]]]:
         """(descriptor fields, pow_rgb, pow_evs, w31) for ops.loss_epilogue, or None when the configuration needs the torch

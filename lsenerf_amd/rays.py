@@ -45,6 +45,29 @@ class RayBundle:
     def __len__(self) -> int:
         return self.origins.shape[0]
 
+    @staticmethod
+    def cat(bundles) -> "RayBundle":
+        """One bundle holding the rays of ``bundles`` in order (autograd flows back to every part).  An optional field must be
+        present in all parts or in none; metadata keys likewise."""
+        bundles = list(bundles)
+        if len(bundles) == 1:
+            return bundles[0]
+
+        def join(name):
+            vals = [getattr(b, name) for b in bundles]
+            if all(v is None for v in vals):
+                return None
+            if any(v is None for v in vals):
+                raise ValueError(f"RayBundle.cat: '{name}' is set on some bundles only")
+            return torch.cat(vals, dim=0)
+        keys = set(bundles[0].metadata)
+        if any(set(b.metadata) != keys for b in bundles):
+            raise ValueError("RayBundle.cat: metadata keys differ between bundles")
+        meta = {k: torch.cat([b.metadata[k] for b in bundles], dim=0) for k in keys}
+        return RayBundle(origins=join("origins"), directions=join("directions"), pixel_area=join("pixel_area"),
+                         camera_indices=join("camera_indices"), nears=join("nears"), fars=join("fars"), times=join("times"),
+                         metadata=meta)
+
 
 @dataclass
 class Frustums:

@@ -14,6 +14,12 @@
  *
  * Float-op order is the one written in the published source, evaluated without FMA contraction and
  * with correctly-rounded division; ties in the boundary sort are resolved stably (lower slot first).
+ *
+ * Second build, -DLSE_ORACLE_FMA (liblse_oracle_fma.so): nvcc contracts a*b+c into fused multiply-adds by default
+ * (-fmad=true), so the shipped nerfacc binary very likely evaluates the four a*b+c sites of grid.cu -- ray start / end
+ * `o + d*(t +- eps)`, `start_index*voxel - ray_start`, `(...)*inv_dir + tmin`, and the marching test `t_last + dt*0.5f` --
+ * with one rounding each.  The LSE_MULADD macro marks exactly those sites; the variant quantifies how many sample
+ * intervals that changes (tests/test_oracle_cpu.py::test_fma_contraction_changes_few_sample_intervals).
  */
 #include <math.h>
 #include <stdint.h>
@@ -21,6 +27,14 @@
 #include <string.h>
 
 #define LSE_MAX_LEVELS 8
+
+#ifdef LSE_ORACLE_FMA
+#define LSE_MULADD(a, b, c) fmaf((a), (b), (c))
+int lse_oracle_fma_build(void) { return 1; }
+#else
+#define LSE_MULADD(a, b, c) ((a) * (b) + (c))
+int lse_oracle_fma_build(void) { return 0; }
+#endif
 
 typedef struct { float x, y, z; } f3;
 
@@ -131,7 +145,7 @@ void lse_oracle_traverse_grids(const float *rays_o, const float *rays_d, int n_r
                 if (step_size <= 0.0f) t_last = this_tmin;
                 else for (;;) {
                     float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                    if (t_last + dt * 0.5f >= this_tmin) break;
+                    if (LSE_MULADD(dt, 0.5f, t_last) >= this_tmin) break;
                     t_last += dt;
                 }
             }
@@ -144,13 +158,13 @@ void lse_oracle_traverse_grids(const float *rays_o, const float *rays_d, int n_r
             int cur[3], fin[3], stp[3], ovf[3];
             for (int a = 0; a < 3; ++a) {
                 voxel[a] = (ab[3 + a] - ab[a]) / res[a];
-                rs[a] = o[a] + d[a] * (this_tmin + eps);
-                re[a] = o[a] + d[a] * (this_tmax - eps);
+                rs[a] = LSE_MULADD(d[a], this_tmin + eps, o[a]);
+                re[a] = LSE_MULADD(d[a], this_tmax - eps, o[a]);
                 cur[a] = clampi((int)(((rs[a] - ab[a]) / (ab[3 + a] - ab[a])) * res[a]), 0, resi[a] - 1);
                 fin[a] = clampi((int)(((re[a] - ab[a]) / (ab[3 + a] - ab[a])) * res[a]), 0, resi[a] - 1);
                 int idelta = d[a] > 0 ? 1 : 0;
                 int start_index = cur[a] + idelta;
-                float tmax_a = ((ab[a] + (((float)start_index * voxel[a]) - rs[a])) * inv[a]) + this_tmin;
+                float tmax_a = LSE_MULADD(ab[a] + LSE_MULADD((float)start_index, voxel[a], -rs[a]), inv[a], this_tmin);
                 tdist[a] = (d[a] == 0.0f) ? this_tmax : tmax_a;
                 float stepf = (d[a] == 0.0f) ? 0.0f : (d[a] > 0.0f ? 1.0f : -1.0f);
                 stp[a] = (int)stepf;
@@ -168,7 +182,7 @@ void lse_oracle_traverse_grids(const float *rays_o, const float *rays_d, int n_r
                     if (step_size <= 0.0f) t_last = t_traverse;
                     else for (;;) {
                         float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                        if (t_last + dt * 0.5f >= t_traverse) break;
+                        if (LSE_MULADD(dt, 0.5f, t_last) >= t_traverse) break;
                         t_last += dt;
                     }
                     continuous = 0;
@@ -178,7 +192,7 @@ void lse_oracle_traverse_grids(const float *rays_o, const float *rays_d, int n_r
                         if (step_size <= 0.0f) t_next = t_traverse;
                         else {
                             float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                            if (t_last + dt * 0.5f >= t_traverse) break;
+                            if (LSE_MULADD(dt, 0.5f, t_last) >= t_traverse) break;
                             t_next = t_last + dt;
                         }
                         if (mode == 1) {

@@ -19,18 +19,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build_c_oracle() -> str:
-    """Compile oracle/c/lse_oracle.c with gcc (no GPU involved).  Returns the .so path."""
+def build_c_oracle(fma: bool = False) -> str:
+    """Compile oracle/c/lse_oracle.c with gcc (no GPU involved).  Returns the .so path.  ``fma``: the build with explicit
+    fused multiply-adds at grid.cu's a*b+c sites (what nvcc's default contraction makes of them)."""
     cdir = os.path.join(_HERE, "c")
-    so = os.path.join(cdir, "liblse_oracle.so")
+    so = os.path.join(cdir, "liblse_oracle_fma.so" if fma else "liblse_oracle.so")
     src = os.path.join(cdir, "lse_oracle.c")
     if (not os.path.exists(so)) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(["make", "-C", cdir, "-s"])
     return so
 
 
-def _lib():
-    global _LIB
+_LIB_FMA = None
+
+
+def _lib(fma: bool = False):
+    global _LIB, _LIB_FMA
+    if fma:
+        if _LIB_FMA is None:
+            _LIB_FMA = ctypes.CDLL(build_c_oracle(True))
+            assert _LIB_FMA.lse_oracle_fma_build() == 1
+        return _LIB_FMA
     if _LIB is None:
         _LIB = ctypes.CDLL(build_c_oracle())
     return _LIB
@@ -63,10 +72,11 @@ def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane=-float("inf"), far_plan
 
 
 def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes=None, step_size=1e-3,
-                   cone_angle=0.0):
+                   cone_angle=0.0, fma: bool = False):
     """nerfacc.grid.traverse_grids as consumed at R:lse_nerf/lse_grid_estimator.py:93-106.
 
-    Returns (ray_indices int64 [N], t_starts f32 [N], t_ends f32 [N], packed_info int64 [R,2])."""
+    Returns (ray_indices int64 [N], t_starts f32 [N], t_ends f32 [N], packed_info int64 [R,2]).  ``fma``: evaluate the a*b+c
+    sites of grid.cu as fused multiply-adds (second build of the C oracle)."""
     o = np.ascontiguousarray(rays_o.detach().cpu().numpy(), dtype=np.float32)
     d = np.ascontiguousarray(rays_d.detach().cpu().numpy(), dtype=np.float32)
     b = np.ascontiguousarray(binaries.detach().cpu().numpy().astype(np.uint8))
@@ -78,7 +88,7 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes=None, far_planes
     far = np.full(R, np.inf, np.float32) if far_planes is None else np.ascontiguousarray(
         far_planes.detach().cpu().numpy(), dtype=np.float32)
     cnts = np.zeros(R, np.int64)
-    f = _lib().lse_oracle_traverse_grids
+    f = _lib(fma).lse_oracle_traverse_grids
 
     def call(mode, starts, ri, ts, te):
         f(_p(o), _p(d), ctypes.c_int(R), _p(b), _p(a), ctypes.c_int(L), ctypes.c_int(rx), ctypes.c_int(ry),

@@ -1,5 +1,10 @@
+import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
+import time
 
 import pytest
 
@@ -8,8 +13,93 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _gpu_tier_selected(config) -> bool:
+    expr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    return "gpu" in expr and "notgpu" not in expr
+
+
+def _dp_test_selected(config) -> bool:
+    """False for subset runs that cannot reach tests/test_gpu_dp.py (explicit other files, a -k that does not name it)."""
+    kw = config.getoption("keyword", "") or ""
+    if kw and "dp" not in kw:
+        return False
+    files = [a.split("::")[0] for a in config.args]
+    for a in files:
+        b = os.path.basename(os.path.normpath(a))
+        if b == "test_gpu_dp.py" or os.path.isdir(a):
+            return True
+    return not files
+
+
+def _launch_dp_rehearsal(config):
+    """Two fresh child processes (torch.distributed.run, gloo, both on cuda:0) BEFORE this process makes any GPU call: ranks must
+    never be spawned from a process that has initialised the GPU.  torch.cuda.device_count() does not initialise it.
+    pytest's output capture is suspended meanwhile, so the rehearsal's progress lines reach the terminal (a silent minutes-long
+    start looks like a hang to whoever runs the suite); the full log is kept for the assertion messages."""
+    import torch
+    if torch.cuda.device_count() < 1:
+        return {"launched": False, "reason": "no GPU visible"}
+    tmp = tempfile.mkdtemp(prefix="lse_dp_")
+    out, log = os.path.join(tmp, "dp_rehearsal.json"), os.path.join(tmp, "dp_rehearsal.log")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dp_rehearsal.py"), "--out", out]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    capman = config.pluginmanager.getplugin("capturemanager")
+    if capman is not None:
+        capman.suspend_global_capture(in_=True)
+    t0 = time.time()
+    rc = None
+    try:
+        print("\n[conftest] 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py) ...", flush=True)
+        with open(log, "w") as lf:
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            try:
+                for line in p.stdout:              # tee: terminal + log file
+                    lf.write(line)
+                    if line.startswith("[dp_rehearsal]") or "Error" in line or "dp_rehearsal:" in line:
+                        print("  " + line.rstrip(), flush=True)
+                    if time.time() - t0 > 900:
+                        p.kill()
+                        lf.write("\n[conftest] killed after 900 s\n")
+                        break
+                rc = p.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                rc = -9
+    finally:
+        if capman is not None:
+            capman.resume_global_capture()
+    with open(log) as lf:
+        tail = lf.read()[-6000:]
+    res = {"launched": True, "returncode": rc, "seconds": time.time() - t0, "log_tail": tail, "report": None, "path": out}
+    if os.path.exists(out):
+        with open(out) as f:
+            res["report"] = json.load(f)
+        keep = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(keep):          # on the GPU box: travels back with the call
+            with open(os.path.join(keep, "dp_rehearsal_pytest.json"), "w") as f:
+                json.dump(res["report"], f, indent=1)
+    return res
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the outcome of the 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py); tests/test_gpu_dp.py asserts on it
+    if not _gpu_tier_selected(config):
+        config._lse_dp_rehearsal = {"launched": False, "reason": "GPU tier not selected"}
+    elif not _dp_test_selected(config):
+        config._lse_dp_rehearsal = {"launched": False, "reason": "subset run that does not include tests/test_gpu_dp.py"}
+    else:
+        config._lse_dp_rehearsal = _launch_dp_rehearsal(config)
+
+
+@pytest.fixture(scope="session")
+def dp_rehearsal(request):
+    return request.config._lse_dp_rehearsal
 
 
 def pytest_collection_modifyitems(config, items):

@@ -208,7 +208,8 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case):
     # (c) the oracle
     lc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
     mapper = {"identity": (lambda x: x), "gt": (lambda x: x ** (1 / 2.4)), "powpow": None}
-    rgb_mapper = (lambda x: x ** pw["rgb"]) if cfg.mapping_method == "powpow" else mapper[cfg.mapping_method]
+    method = cfg.mapping_method if cfg.use_mapping else "identity"        # (the config's default "mlp" is only read with use_mapping)
+    rgb_mapper = (lambda x: x ** pw["rgb"]) if method == "powpow" else mapper[method]
     evs_mapper = None
     if cfg.evs_mapping_method is not None:
         evs_mapper = (lambda x: x ** pw["evs"]) if cfg.evs_mapping_method == "powpow" else mapper[cfg.evs_mapping_method]
@@ -317,3 +318,76 @@ def test_config4_pose_parameters_receive_gradients_through_the_hot_path():
     torch.autograd.backward([rbc.origins, rbc.directions], [oc.grad, dc.grad])
     assert float(spl_c.ctrl_tangents.grad.abs().max()) > 0
     assert nmax_err(spl_g.ctrl_tangents.grad, spl_c.ctrl_tangents.grad) < 2 * TOL_GRAD
+
+
+@pytest.mark.parametrize("emb_type", ["global_emb", "evs_emb"])
+def test_train_step_bundles_equals_three_separate_passes(emb_type):
+    """The reference's training step (R:lse_nerf/lse_pipeline.py:110-145: colour, previous-event and next-event bundle, one
+    model forward each) as ONE packed pass (LSENeRFModel.train_step_bundles): with the same stratified offsets every ray gets
+    the same samples and the same rendered values as in a pass of its own -- asserted exactly for the sample counts, to
+    rounding for the renders -- the losses agree, and every gradient (table, MLPs, embedding, mapper scalars, per-ray poses)
+    agrees within the gradient tolerance (one hash scatter over all bundles sums in a different order than three).  Default
+    configuration of the path: cone 0.004, alpha_thre 0.01 -> visibility pre-pass on."""
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, LSEEmbeddingConfig, RayBundle
+    from tests.util import random_binaries
+    torch.manual_seed(96)
+    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, use_mapping=True, mapping_method="identity",
+                             map_mode="co_map", evs_mapping_method="powpow", ev_one_dim="learned",
+                             embed_config=LSEEmbeddingConfig(embedding_type=emb_type))
+    hip = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 16)
+    with torch.no_grad():
+        hip.field.mlp_base_grid.params.mul_(300.0)
+        hip.evs_mapper.pow_coeff.fill_(0.8)
+    hip = hip.cuda().train()
+    hip.occupancy_grid.binaries.copy_(random_binaries(2, 32, 0.5, 3).cuda())
+    hip.occupancy_grid.occs.copy_(hip.occupancy_grid.binaries.flatten().float() * 0.5)
+    g = torch.Generator().manual_seed(11)
+    sizes = (232, 60, 60)                                       # 2316 / 597 / 597 scaled by 10
+    bundles, jit = [], []
+    for i, n in enumerate(sizes):
+        o, d = random_rays(n, seed=30 + i)
+        meta = {"appearance_id": torch.randint(0, 16, (n,), generator=g).cuda()}
+        bundles.append(RayBundle(origins=o.cuda().requires_grad_(True), directions=d.cuda().requires_grad_(True),
+                                 camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"), metadata=meta))
+        jit.append(torch.rand(n, generator=g).cuda())
+    batch = {"col_batch": {"image": torch.rand(sizes[0], 3, generator=g).cuda()},
+             "evs_batch": {"image": ((torch.rand(sizes[1], 1, generator=g) - 0.5) * 0.4).cuda()}}
+    params = {"grid": hip.field.mlp_base_grid.params, "base": hip.field.mlp_base_mlp.params, "head": hip.field.mlp_head.params,
+              "emb": hip.field.embedding_appearance.embedding.weight, "pow": hip.evs_mapper.pow_coeff, "w31": hip.rgb_to_one.weights}
+
+    def grads():
+        out = {k: p.grad.clone() for k, p in params.items()}
+        out.update({f"o{i}": b.origins.grad.clone() for i, b in enumerate(bundles)})
+        out.update({f"d{i}": b.directions.grad.clone() for i, b in enumerate(bundles)})
+        for p in params.values():
+            p.grad = None
+        for b in bundles:
+            b.origins.grad = b.directions.grad = None
+        return out
+
+    # (i) the reference's composition: three forwards
+    raws = [hip.exec_get_outputs(b, jitter=j) for b, j in zip(bundles, jit)]
+    l3 = hip.fused_loss_dict({"col_out": raws[0], "prev_out": raws[1], "next_out": raws[2]}, batch)
+    sum(l3.values()).backward()
+    g3 = grads()
+    # (ii) one packed pass
+    out, l1, metrics = hip.train_step_bundles(bundles[0], bundles[1], bundles[2], batch, jitter=torch.cat(jit), with_metrics=True)
+    sum(l1.values()).backward()
+    g1 = grads()
+    assert set(l1) == set(l3) == {"rgb_loss", "event_loss"}
+    for k, r in zip(("col_out", "prev_out", "next_out"), raws):
+        assert torch.equal(out[k]["num_samples_per_ray"], r["num_samples_per_ray"]), k
+        assert int(r["num_samples_per_ray"].sum()) > 20 * r["rgb"].shape[0]
+        for key in ("rgb", "accumulation", "depth"):
+            assert nmax_err(out[k][key], r[key]) < 1e-6, (k, key)
+    for k in l3:
+        assert abs(float(l1[k]) - float(l3[k])) < 1e-6 * max(1.0, abs(float(l3[k]))), k
+    for k in g3:
+        assert nmax_err(g1[k], g3[k], 1e-12) < TOL_GRAD, k
+    assert set(metrics) == {"col_psnr", "col_num_samples_per_batch"}
+    assert int(metrics["col_num_samples_per_batch"]) == int(raws[0]["num_samples_per_ray"].sum())
+    # colour-only step (BASELINE config 4's composition: no event bundles)
+    out_c, l_c, _ = hip.train_step_bundles(bundles[0], None, None, {"col_batch": batch["col_batch"], "evs_batch": None}, jitter=jit[0])
+    assert set(l_c) == {"rgb_loss"} and out_c["prev_out"] is None and abs(float(l_c["rgb_loss"]) - float(l3["rgb_loss"])) < 1e-6
+    with pytest.raises(ValueError, match="pairs"):
+        hip.train_step_bundles(bundles[0], bundles[1], None, batch)

@@ -41,6 +41,38 @@ def test_traverse_bit_exact(levels, res, cone, step):
     assert torch.equal(hte.cpu(), te), "t_ends differ bitwise"
 
 
+def test_traverse_fma_setup_is_bit_exact_against_the_fma_oracle():
+    """Option "traverse_fma": the a*b+c sites of the traversal set-up as fused multiply-adds, i.e. what nvcc's default
+    contraction makes of nerfacc's grid.cu.  1024 sphere rays through a carved 4-level 128^3 grid with cone-angle steps (the
+    workload on which the two arithmetic conventions differ in about one interval per million,
+    tests/test_oracle_cpu.py::test_fma_contraction_changes_few_sample_intervals): the kernel with the option on equals the FMA
+    build of the C oracle bit for bit, with the option off the strict build -- each setting is exact against its own oracle."""
+    from oracle import sampling as osamp
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(96)
+    R = 1024
+    o = torch.randn(R, 3, generator=g)
+    o = 1.5 * o / o.norm(dim=-1, keepdim=True)
+    d = (torch.rand(R, 3, generator=g) - 0.5) - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    aabbs = torch.stack([osamp.enlarge_aabb(torch.tensor([-1.0, -1, -1, 1, 1, 1]), 2 ** i) for i in range(4)])
+    step = float(np.float32(2 * np.sqrt(3.0) / 1000))
+    near, far = torch.full((R,), 0.05), torch.full((R,), 1e3)
+    b = torch.rand(4, 128, 128, 128, generator=g) < 0.43
+    try:
+        for fma in (1, 0):
+            _lib.set_option("traverse_fma", fma)
+            ri, ts, te, packed = osamp.traverse_grids(o, d, b, aabbs, near, far, step, 0.004, fma=bool(fma))
+            hri, hts, hte, hpacked = ops.traverse_grids(o.cuda(), d.cuda(), b.cuda().view(torch.uint8), aabbs.cuda(), near.cuda(),
+                                                        far.cuda(), step, 0.004)
+            assert ri.numel() > 300_000
+            assert torch.equal(hpacked.cpu(), packed), fma
+            assert torch.equal(hri.cpu().long(), ri) and torch.equal(hts.cpu(), ts) and torch.equal(hte.cpu(), te), fma
+    finally:
+        _lib.set_option("traverse_fma", 0)
+
+
 @pytest.mark.parametrize("levels,res,cone,step", [(1, 32, 0.0, 0.01), (4, 32, 0.004, 0.005), (4, 128, 0.0, 0.0034641)])
 def test_traverse_single_pass_equals_two_pass(levels, res, cone, step):
     """The single-pass marcher (fixed-capacity ray slots + compaction) returns the two-pass result bit for bit; a violated

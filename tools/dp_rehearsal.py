@@ -26,8 +26,15 @@ configuration (cone 0.004, alpha_thre 0.01 => sigma_fn pre-pass on, 4-level 128^
     "grids_identical_before_the_broadcast": true in a quiet process, occasionally false in the last bits when two
     processes share one GPU as here), and dist.sync_grid then broadcasts rank 0's grid, which is what is asserted
     (the reference relies on DDP's buffer broadcast alone).
+Ranks TAKE TURNS on the GPU (``--concurrent`` switches that off): every compute phase -- model construction, grid refresh,
+forward + backward, optimizer kernel -- runs on one rank at a time, bracketed by ``torch.cuda.synchronize()`` and a barrier,
+and only the collectives run on all ranks together.  One process per GPU is the production layout and the only one the
+kernels are specified for; two processes with kernels in flight on ONE card is an artefact of rehearsing W = 2 on a one-GPU
+box, and round 2 saw hash-feature lines there that a re-evaluation did not reproduce (audit).  With
+turns, each rank has the card to itself while it computes, so the rehearsal checks what it is meant to check -- sharding,
+exchange, hook placement, rank-consistent grids -- on the values one process per GPU produces.
 Launch it BEFORE anything else touches the GPU in the calling shell command; ranks must not be spawned from a process
-that has initialised the GPU.
+that has initialised the GPU (tests/conftest.py does so from pytest_configure).
 """
 from __future__ import annotations
 
@@ -44,6 +51,29 @@ sys.path.insert(0, ROOT)
 
 RAYS = 4096
 STEPS = 3
+CONCURRENT = False      # --concurrent: all ranks compute at the same time on the shared GPU (round-2 behaviour)
+TURN_GROUP = None       # a process group of its own for the turn barriers: the data path's collectives are issued inside turns
+                        # (GradPipeline.start, the early all-reduce of the overlapped exchange), i.e. in a different order
+                        # relative to the barriers on different ranks -- collectives of ONE group must be issued in the same order
+                        # everywhere, so the barriers cannot share the data path's group
+
+
+def progress(rank, *a):
+    if rank == 0:
+        print("[dp_rehearsal]", *a, flush=True)
+
+
+def in_turns(rank: int, world: int, single: bool, fn):
+    """Run ``fn`` on one rank at a time (see the module docstring); returns this rank's result."""
+    if single or CONCURRENT or world == 1:
+        return fn()
+    out = None
+    for r in range(world):
+        if r == rank:
+            out = fn()
+            torch.cuda.synchronize()
+        tdist.barrier(group=TURN_GROUP)
+    return out
 
 
 def make_model(dev):
@@ -69,15 +99,20 @@ def make_batch(dev):
 
 
 def run(mode: str, rank: int, world: int, dev, batch):
-    """Returns (flat parameters, samples rendered by this rank per step, grid consistency flags)."""
+    """Returns (flat parameters, samples rendered by this rank per step, grid consistency flags, ...)."""
     from lsenerf_amd import RayBundle, dist as ldist
     from lsenerf_amd.optim import FlatAdam, FlatParams
     single = mode == "single"
     w = 1 if single else world
     sl = slice(0, RAYS) if single else ldist.shard_rays(RAYS, rank, world)
-    model = make_model(dev)
-    torch.manual_seed(1000 + rank)                                 # R:train.py:104: every rank its own global RNG from here on
-    flat = FlatParams(model.get_param_groups()["fields"], total_multiple=world * 64)
+    turns = lambda fn: in_turns(rank, world, single, fn)
+
+    def build():
+        model = make_model(dev)
+        torch.manual_seed(1000 + rank)                             # R:train.py:104: every rank its own global RNG from here on
+        return model, FlatParams(model.get_param_groups()["fields"], total_multiple=world * 64)
+    progress(rank, mode, "build")
+    model, flat = turns(build)
     if not single:
         ldist.broadcast_params(flat.data)
     opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
@@ -93,72 +128,53 @@ def run(mode: str, rank: int, world: int, dev, batch):
     rb = RayBundle(origins=batch["o"][sl].clone().requires_grad_(True), directions=batch["d"][sl].clone().requires_grad_(True),
                    camera_indices=torch.zeros(sl.stop - sl.start, 1, dtype=torch.long, device=dev),
                    metadata={"appearance_id": batch["aid"][sl]})
-    refresh = model.update_occupancy_grid
-    grids_ok = []
-    pre_sync = []
-    if not single:     # rank 0's grid after every refresh; what the ranks computed on their own is recorded first
-        model.occupancy_grid.after_update_hook = lambda: (pre_sync.append(ldist.check_grid_consistency(model.occupancy_grid)),
-                                                          ldist.sync_grid(model.occupancy_grid))
+    grids_ok, pre_sync = [], []
 
     def refresh_grid(step):
-        if pipe is not None:
-            pipe.flush()                                           # the refresh reads the parameters
-        refresh(step)
+        # the refresh reads the parameters: finish a pending exchange first.  The compute runs in turns; what
+        # dist.attach_grid_sync does inside the estimator's after_update_hook in production -- record whether the ranks
+        # agreed on their own, then broadcast rank 0's grid -- runs here right after it, on all ranks together.
+        def compute():
+            if pipe is not None:
+                pipe.flush()
+            model.update_occupancy_grid(step)
+        turns(compute)
+        if not single:
+            pre_sync.append(ldist.check_grid_consistency(model.occupancy_grid))
+            ldist.sync_grid(model.occupancy_grid)
         grids_ok.append(True if single else ldist.check_grid_consistency(model.occupancy_grid))
 
-    if not single and os.environ.get("LSE_DIAG"):
-        # which stage of the density evaluation differs between the ranks (same parameters, same cells)?
-        est, fld = model.occupancy_grid, model.field
-
-        def cks(t):
-            v = t.detach().contiguous().view(-1)
-            v = (v.to(torch.uint8) if v.dtype == torch.bool else v)
-            v = (v.view(torch.int32) if v.element_size() == 4 else v).to(torch.int64)
-            w = (torch.arange(v.numel(), device=v.device) % 1000003) + 1
-            return torch.stack([v.sum(), (v * w).sum()])
-        names, vals, keep = [], [], {}
-        names.append("params"); vals.append(cks(flat.data))
-        for lvl, (indices, x) in enumerate(est._update_samples(0, 256, est._update_generator(0))):
-            with torch.no_grad():
-                x01, sel = fld._x01(x.reshape(-1, 3).contiguous(), None, None, None, None, None)
-                y = fld.mlp_base_grid.forward_levelmajor(x01)
-                h, sigma = fld._base_mlp(y, sel, x01.shape[0])
-            for nm, t in (("x", x), ("x01", x01), ("y", y), ("h", h), ("sigma", sigma)):
-                names.append(f"{nm}{lvl}"); vals.append(cks(t))
-            keep[lvl] = (x01, y)
-        mine = torch.stack(vals)
-        other = mine.clone()
-        tdist.broadcast(other, src=0)
-        bad = [names[i] for i in range(len(names)) if not torch.equal(other[i], mine[i])]
-        if rank == 1:
-            print("DIAG", mode, "stages that differ from rank 0:", bad, flush=True)
-            for lvl, (x01, y) in keep.items():
-                if f"y{lvl}" in bad and f"x01{lvl}" not in bad:
-                    y2 = fld.mlp_base_grid.forward_levelmajor(x01)
-                    ne = (y2 != y).any(dim=2)
-                    print("DIAG   level-eval", lvl, ": re-evaluated y equals first y:", bool(torch.equal(y2, y)), "differing samples per table level",
-                          ne.sum(dim=1).tolist(), flush=True)
     refresh_grid(0)
+    progress(rank, mode, "grid refreshed at step 0")
     n_samples = []
     first_grad = None
     for step in range(STEPS):
-        rb.origins.grad = rb.directions.grad = None
-        if exchange is not None:
-            exchange.begin_step(1)
-        # pipelined: sampling() fires GradPipeline.flush after the marcher and before the sigma_fn pre-pass
-        out = model.exec_get_outputs(rb, jitter=batch["jitter"][sl])
-        opt.zero_grad()
-        loss = torch.nn.functional.mse_loss(out["rgb"], batch["target"][sl])
-        loss.backward()
-        n_samples.append(int(out["num_samples_per_ray"].sum()))
+        def fwd_bwd():
+            rb.origins.grad = rb.directions.grad = None
+            if exchange is not None:
+                exchange.begin_step(1)
+            # pipelined: sampling() fires GradPipeline.flush after the marcher and before the sigma_fn pre-pass (the all-reduce
+            # it waits for was started by every rank in its previous turn)
+            out = model.exec_get_outputs(rb, jitter=batch["jitter"][sl])
+            opt.zero_grad()
+            loss = torch.nn.functional.mse_loss(out["rgb"], batch["target"][sl])
+            loss.backward()
+            n = int(out["num_samples_per_ray"].sum())
+            if pipe is not None:
+                if step == 0:
+                    fwd_bwd.g0 = flat.grad.clone()
+                pipe.start()
+            return n
+        n_samples.append(turns(fwd_bwd))
+        progress(rank, mode, "step", step, "samples on this rank", n_samples[-1])
         if step == 0:                                              # rank-averaged gradient of the first step
-            first_grad = flat.grad.clone()
+            first_grad = fwd_bwd.g0 if pipe is not None else flat.grad.clone()
             if not single:
                 ldist.allreduce_grads(first_grad)
                 first_grad /= w
         if pipe is not None:
-            pipe.start()
-        elif sharded is not None:
+            continue
+        if sharded is not None:
             sharded.lr = opt.current_lr()
             opt.step_count += 1
             sharded.step()
@@ -167,9 +183,9 @@ def run(mode: str, rank: int, world: int, dev, batch):
                 exchange.finish()
             elif not single:
                 ldist.allreduce_grads(flat.grad)
-            opt.step(grad_scale=1.0 / w)
+            turns(lambda: opt.step(grad_scale=1.0 / w))
     if pipe is not None:
-        pipe.flush()
+        turns(pipe.flush)
     refresh_grid(320)
     if exchange is not None:
         exchange.uninstall()
@@ -182,18 +198,37 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dp_rehearsal.json"))
     ap.add_argument("--modes", default="plain,pipelined,sharded,overlap")
+    ap.add_argument("--concurrent", action="store_true", help="all ranks compute at the same time on the shared GPU")
     args = ap.parse_args()
+    global CONCURRENT
+    CONCURRENT = args.concurrent
     from lsenerf_amd import _lib, dist as ldist
     rank, world, _ = ldist.init_from_env("gloo")
     assert world >= 2, "launch with torch.distributed.run --nproc-per-node 2"
+    global TURN_GROUP
+    TURN_GROUP = tdist.new_group(backend="gloo")
     assert torch.cuda.is_available(), "the rehearsal trains the HIP model: it needs the MI355X"
     dev = torch.device("cuda", 0)                                  # all ranks share the one GPU of the box
     torch.cuda.set_device(dev)
     _lib.load()
     batch = make_batch(dev)
 
-    ref, n_ref, _, occ_ref, g_ref, spans = run("single", rank, world, dev, batch)   # every rank: the same full-batch reference
-    ref2, _, _, _, g_ref2, _ = run("single", rank, world, dev, batch)               # ... twice: the run-to-run floor
+    # ONE process trains on the whole batch -- twice, for the run-to-run floor -- while the other ranks wait; its results
+    # are then broadcast (every rank needs them for its own comparison)
+    if rank == 0 or CONCURRENT:
+        ref, n_ref, _, occ_ref, g_ref, spans = run("single", rank, world, dev, batch)
+        ref2, _, _, _, g_ref2, _ = run("single", rank, world, dev, batch)
+        torch.cuda.synchronize()
+    if not CONCURRENT:
+        box = [None]
+        if rank == 0:
+            box = [{"n_ref": n_ref, "occ_ref": occ_ref, "spans": spans, "numel": ref.numel()}]
+        tdist.broadcast_object_list(box, src=0)
+        n_ref, occ_ref, spans = box[0]["n_ref"], box[0]["occ_ref"], box[0]["spans"]
+        if rank != 0:
+            ref, ref2, g_ref, g_ref2 = (torch.empty(box[0]["numel"], dtype=torch.float32, device=dev) for _ in range(4))
+        for t in (ref, ref2, g_ref, g_ref2):
+            tdist.broadcast(t, src=0)
     scale = float(ref.abs().max())
 
     def grad_err(g):        # per parameter tensor: max|g - g_ref| / max|g_ref|
@@ -216,12 +251,15 @@ def main():
                            "and max|p_dp - p_single| <= max(1e-6 * max|p|, 3 x run-to-run max diff); samples per step "
                            "within 1e-5 relative (visibility-threshold flips on parameters that differ in the last bits)",
               "max_abs_param": scale, "modes": {},
-              "note": "Two processes share ONE GPU here, which the production layout (one process per GPU) never does.  In that "
-                      "situation ~0.3 % of the kernel launches of EITHER process were seen to return one 128-byte line of hash "
-                      "features that a re-evaluation of the same inputs does not reproduce (tools/refresh_determinism.py: 0 of "
-                      "1200 evaluations differ when the process has the GPU to itself).  Such an event flips a visibility decision "
-                      "or an occupancy bit on one rank; the grid broadcast (dist.sync_grid) contains the second, the first can push "
-                      "a mode over the parameter tolerance -- rerun in that case (about one run in four is affected)."}
+              "gpu_sharing": "concurrent" if CONCURRENT else "ranks take turns on the GPU (one process at a time has kernels in "
+                             "flight); collectives run on all ranks together",
+              "note": "W = 2 is rehearsed on a one-GPU box, which one process per GPU (the production layout) never shares.  Round 2 "
+                      "ran both ranks' kernels concurrently and saw, in about 0.3 % of the launches of either process, one 128-byte "
+                      "line of hash features that a re-evaluation of the same inputs did not reproduce (never with one process on "
+                      "the card: tools/refresh_determinism.py, 0 of 1200); the static audit of every buffer hand-off found no cause "
+                      "in this code (DESIGN.md section 7).  Since round 3 the ranks take turns on the card, so every number below is "
+                      "what one process per GPU computes; 'grids_identical_before_the_broadcast' records whether the ranks' own "
+                      "refreshes agreed before dist.sync_grid ran."}
     ok_all = True
     for mode in args.modes.split(","):
         p, n_s, grids_ok, occ, g1, _ = run(mode, rank, world, dev, batch)
