@@ -228,6 +228,95 @@ def context_inside_box(device, steps=12, warmup=4):
             "hash_bwd_alg_GBps": HASH_BYTES_PER_SAMPLE * n / (kern.get("lse_hash_bwd", 1e9) * 1e-3) / 1e9}
 
 
+def context_composition(device, kind, steps=16, warmup=6):
+    """The step LSENeRF actually trains with (R:lse_nerf/lse_pipeline.py:110-145), as ONE packed pass
+    (LSENeRFModel.train_step_bundles), in the reference's default configuration of the path (cone 0.004, alpha_thre 0.01,
+    pre-pass on, carved 4-level 128^3 grid, refresh every 16 steps inside the timing; trained-like synthetic field):
+      kind "cfg2": colour + previous-event + next-event bundle, 2316 / 597 / 597 rays (R:lse_nerf/lse_datamanager.py:135-144),
+                   co_map routing, identity rgb mapper, powpow event mapper, learned ThreeToOne, rgb MSE + log-intensity event loss
+                   (R:exp_configs/lsenerf_config.sh);
+      kind "cfg4": BAD-NeRF: rgb only, 878 pixels x 4 virtual cameras = 3512 rays averaged per pixel (deblur), gradients w.r.t.
+                   every ray's origin and direction for the pose optimiser (R:exp_configs/BADNERF_config.sh)."""
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    torch.manual_seed(96)
+    if kind == "cfg2":
+        cfg = LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow")
+        sizes = (2316, 597, 597)
+    else:
+        cfg = LSENeRFModelConfig(use_mapping=False, map_mode="None", evs_mapping_method="None", rgb_loss_type="deblur")
+        sizes = (878 * 4, 0, 0)
+    model = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(device).train()
+    with torch.no_grad():
+        model.field.mlp_base_grid.params.mul_(3000.0)
+        model.field.mlp_base_mlp.params[-16 * 64:-15 * 64].mul_(6.0)
+    flat = FlatParams(model.get_param_groups()["fields"])
+    opt = FlatAdam(flat, lr=1e-3, eps=1e-15)
+    g = torch.Generator().manual_seed(7)
+
+    def bundle(o, d):
+        n = o.shape[0]
+        return RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
+                         camera_indices=torch.zeros(n, 1, dtype=torch.long, device=device),
+                         metadata={"appearance_id": torch.randint(0, 64, (n,), generator=g).to(device)})
+    if kind == "cfg2":
+        o, d = sphere_rays(sizes[0], g)
+        col = bundle(o, d)
+        o, d = sphere_rays(sizes[1], g)
+        prev = bundle(o, d)
+        o2 = o + 0.01 * torch.randn(o.shape, generator=g)          # the same pixels from the neighbouring event camera
+        d2 = d + 0.01 * torch.randn(d.shape, generator=g)
+        nxt = bundle(o2, d2 / d2.norm(dim=-1, keepdim=True))
+        batch = {"col_batch": {"image": torch.rand(sizes[0], 3, generator=g).to(device)},
+                 "evs_batch": {"image": ((torch.rand(sizes[1], 1, generator=g) - 0.5) * 0.4).to(device)}}
+    else:
+        o, d = sphere_rays(878, g)
+        o4 = (o[:, None, :] + 0.005 * torch.randn(878, 4, 3, generator=g)).reshape(-1, 3)
+        d4 = d[:, None, :] + 0.005 * torch.randn(878, 4, 3, generator=g)
+        col, prev, nxt = bundle(o4, (d4 / d4.norm(dim=-1, keepdim=True)).reshape(-1, 3)), None, None
+        batch = {"col_batch": {"image": torch.rand(878, 3, generator=g).to(device)}, "evs_batch": None}
+    for s_ in range(0, 64, 16):
+        model.update_occupancy_grid(s_)
+    last = {}
+
+    def step(i):
+        model.update_occupancy_grid(65 + i)
+        opt.zero_grad()
+        for b in (col, prev, nxt):
+            if b is not None:
+                b.origins.grad = b.directions.grad = None
+        out, losses, _ = model.train_step_bundles(col, prev, nxt, batch)
+        sum(losses.values()).backward()
+        opt.step()
+        last["out"] = out
+
+    from lsenerf_amd import ops as _ops
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    _ops.SYNC_STATS.update(seconds=0.0, count=0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    host_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    blocked, n_sync = _ops.SYNC_STATS["seconds"], _ops.SYNC_STATS["count"]
+    kern, launches = _event_pass(step, warmup + steps, 8, None)
+    kept = sum(int(v["num_samples_per_ray"].sum()) for v in last["out"].values() if v is not None)
+    rays = sum(sizes)
+    return {"workload": {"cfg2": "colour + prev + next event bundle (2316 / 597 / 597 rays), co_map routing, rgb + event loss",
+                         "cfg4": "BAD-NeRF deblur: 878 pixels x 4 virtual cameras = 3512 rays, rgb loss on the 4-ray mean, pose gradients"}[kind]
+                        + "; ONE packed pass per step (train_step_bundles), reference default sampler configuration, carved grid, "
+                          "refresh every 16 steps inside the timing",
+            "rays": rays, "steps": steps, "ms_per_step": ms, "rays_per_s": rays / (ms * 1e-3),
+            "samples_per_ray_after_culling": kept / rays, "host_issue_ms_per_step": host_issue / steps * 1e3,
+            "host_blocked_in_count_readbacks_ms_per_step": blocked / steps * 1e3, "count_readbacks_per_step": n_sync / steps,
+            "host_python_ms_per_step": (host_issue - blocked) / steps * 1e3,
+            "launches_per_step": sum(launches.values()), "kernel_ms_sum_per_step": sum(kern.values()),
+            "kernel_ms_per_step": kern}
+
+
 def context_m_packed(device, steps=12, warmup=4):
     """SURVEY.md 8d 'M-packed' (kernel roofline inputs): the estimator is bypassed; 4096 rays from the radius-1.5 sphere,
     ray_indices = repeat_interleave(arange(R), 1024), t_starts = 0.05 + k * step, t_ends = t_starts + step."""
@@ -441,6 +530,10 @@ def main():
             line["default_config"] = context_default_config(device)
             torch.cuda.empty_cache()
             line["m_packed"] = context_m_packed(device)
+            torch.cuda.empty_cache()
+            line["cfg2_composition"] = context_composition(device, "cfg2")
+            torch.cuda.empty_cache()
+            line["cfg4_composition"] = context_composition(device, "cfg4")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

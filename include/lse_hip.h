@@ -180,6 +180,12 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *   coarse_levels the levels below this one are processed first by a cache-free kernel at high occupancy (lane = sample, run
  *                     ends transposed through a 1.5 KB staging area, 16 lanes per run add straight to memory); every value is
  *                     correct, the split only moves time between the two kernels
+ *   replicas, replica_levels, workspace, workspace_bytes
+ *                 the coarsest levels are a few thousand 64-byte lines that EVERY wave of a launch adds to, and the memory-side
+ *                 atomic units serialise requests to one line: the direct adds (few_runs path, coarse kernel) of the levels below
+ *                 replica_levels (default 4: 1 MB of table) go to one of `replicas` (default 16, a power of two) zero-initialised copies
+ *                 in `workspace`, chosen by the workgroup index, and a small kernel folds them into dtable at the end of the call
+ *                 (leaving the workspace zero).  workspace == NULL (lse_hash_bwd, lse_hash_bwd_levels): no replicas, same values
  *   dbg           timing experiments only (bit 0: skip flush atomics, bit 1: skip run ends, bit 2: skip the scan) -> WRONG results
  * lse_hash_bwd / lse_hash_bwd_levels use lse_hash_bwd_default_opts(). */
 typedef struct lse_hash_bwd_opts {
@@ -187,8 +193,13 @@ typedef struct lse_hash_bwd_opts {
     float interleave_from_scale;
     int32_t stage_max;
     int32_t coarse_levels;
+    int32_t replicas, replica_levels;
+    void *workspace;            /* device memory, zero on entry, zero again when the call's kernels have run; NULL = no replicas */
+    int64_t workspace_bytes;
 } lse_hash_bwd_opts;
 void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
+/* bytes of `workspace` that lse_hash_bwd_ex needs for opts->replicas x the levels below opts->replica_levels (NULL = defaults) */
+int64_t lse_hash_bwd_workspace_bytes(const lse_grid_desc *desc, const lse_hash_bwd_opts *opts);
 int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
                     float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end, int64_t n,
                     const lse_hash_bwd_opts *opts /* NULL = defaults */, lse_stream_t stream);

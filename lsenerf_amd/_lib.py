@@ -26,7 +26,8 @@ class GridDesc(Structure):
 
 class HashBwdOpts(Structure):
     _fields_ = [("impl", c_int32), ("gran", c_int32), ("few_runs", c_int32), ("second_probe", c_int32), ("rounds", c_int32),
-                ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32), ("coarse_levels", c_int32)]
+                ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32), ("coarse_levels", c_int32),
+                ("replicas", c_int32), ("replica_levels", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 class EpilogueDesc(Structure):
@@ -118,6 +119,8 @@ def load():
         fn.restype = c_int32
     lib.lse_hash_bwd_default_opts.restype = None
     lib.lse_hash_bwd_default_opts.argtypes = [POINTER(HashBwdOpts)]
+    lib.lse_hash_bwd_workspace_bytes.restype = c_int64
+    lib.lse_hash_bwd_workspace_bytes.argtypes = [POINTER(GridDesc), POINTER(HashBwdOpts)]
     v = lib.lse_abi_version()
     if v != LSE_ABI_VERSION:
         raise LseHipError(f"liblse_hip.so ABI version {v} != binding version {LSE_ABI_VERSION}")
@@ -136,17 +139,21 @@ def load():
 TIMING = None
 
 
+_TIMING_ALIAS = {"lse_hash_bwd_ex": "lse_hash_bwd", "lse_hash_bwd_levels": "lse_hash_bwd"}   # one operation, three entry points
+
+
 def call(name: str, *args):
     lib = load()
     t = TIMING
-    if t is not None and (t["names"] is None or name in t["names"]):
+    tname = _TIMING_ALIAS.get(name, name)
+    if t is not None and (t["names"] is None or tname in t["names"]):
         import torch
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        t["events"].append((name, e0, e1))
+        t["events"].append((tname, e0, e1))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -24,6 +24,10 @@ struct GridParams {
     int n_levels;
     int l_begin, l_end;   // backward only: levels [l_begin, l_end) of this launch
     int dx_accumulate;    // backward only: dx += instead of dx = (second launch of a split backward)
+    // backward only: the direct (cache-free) adds of levels < rep_levels go to one of rep_mask + 1 replicas of those levels'
+    // gradient (workspace, rep_stride floats apart, chosen by the workgroup index) instead of the table gradient itself
+    int rep_levels, rep_mask;
+    uint32_t rep_stride;
     uint32_t offsets[LSE_MAX_GRID_LEVELS + 1];
     float scales[LSE_MAX_GRID_LEVELS];
     uint32_t res[LSE_MAX_GRID_LEVELS];
@@ -714,7 +718,8 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg, int few_runs, int second_probe, int stage_max)
+                                                              int64_t n, int dbg, int few_runs, int second_probe, int stage_max,
+                                                              float *__restrict__ ws)
 {
     constexpr int kRounds = 1;                 // one 64-sample round per wave
     constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
@@ -956,7 +961,13 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 
     for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
-        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;      // (few-runs path only)
+        // (few-runs path only)  The coarsest levels are a few thousand lines that every wave of the launch adds to: the
+        // memory-side units serialise same-line requests (M-packed: 5 % of the kernel's requests, 0.6 of its 3.6 ms), so
+        // those adds go to one of several replicas of the level, picked by the workgroup index, and
+        // hash_bwd_reduce_replicas_kernel folds the replicas into the table gradient afterwards
+        float *__restrict__ dt = (ws != nullptr && l < g.rep_levels)
+                                     ? ws + (size_t)(blockIdx.x & (unsigned)g.rep_mask) * g.rep_stride + 2 * (size_t)li.offset
+                                     : dtable + 2 * (size_t)li.offset;
         const float2 *__restrict__ tab = table + li.offset;
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
@@ -1044,7 +1055,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     for (int r0 = lane >> 4; r0 < n_ends; r0 += 4) {
                         const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
                         const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
-                        if (a != 0.f) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
+                        if (a != 0.f && !(dbg & 16)) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1122,7 +1133,7 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg)
+                                                              int64_t n, int dbg, float *__restrict__ ws)
 {
     constexpr int kBatch = 16;                      // run ends per staging trip
     __shared__ uint32_t s_stage[4][kBatch * 24];    // [run][8 idx | 16 sums]
@@ -1139,7 +1150,9 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
 
     for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
-        float *__restrict__ dt = dtable + 2 * (size_t)li.offset;
+        float *__restrict__ dt = (ws != nullptr && l < g.rep_levels)
+                                     ? ws + (size_t)(blockIdx.x & (unsigned)g.rep_mask) * g.rep_stride + 2 * (size_t)li.offset
+                                     : dtable + 2 * (size_t)li.offset;
         const float2 *__restrict__ tab = table + li.offset;
         float w0, w1, w2;
         uint32_t p0, p1, p2;
@@ -1229,6 +1242,29 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
     }
 }
 
+// dtable[i] += sum over replicas; the workspace reads zero again afterwards (it is handed over zeroed and returned zeroed)
+__global__ __launch_bounds__(256) void hash_bwd_reduce_replicas_kernel(float *__restrict__ ws, float *__restrict__ dtable,
+                                                                       uint32_t n4, int n_rep, uint32_t stride)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < n_rep; ++r) {
+        float4 *p = reinterpret_cast<float4 *>(ws + (size_t)r * stride) + i;
+        const float4 v = *p;
+        if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            *p = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (s.x != 0.f || s.y != 0.f || s.z != 0.f || s.w != 0.f) {
+        float4 *d = reinterpret_cast<float4 *>(dtable) + i;
+        float4 t = *d;
+        t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+        *d = t;
+    }
+}
+
 int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
 {
     LSE_REQUIRE(desc, "%s: null desc", who);
@@ -1239,6 +1275,9 @@ int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
     g.l_begin = 0;
     g.l_end = desc->n_levels;
     g.dx_accumulate = 0;
+    g.rep_levels = 0;
+    g.rep_mask = 0;
+    g.rep_stride = 0;
     for (int l = 0; l <= desc->n_levels; ++l) g.offsets[l] = desc->offsets[l];
     for (int l = 0; l < desc->n_levels; ++l) {
         LSE_REQUIRE(desc->offsets[l + 1] > desc->offsets[l], "%s: level %d is empty", who, l);
@@ -1283,6 +1322,28 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     o->dbg = 0;
     o->interleave_from_scale = 1e30f;   // measured negative on MI355X (same-address lanes of one atomic instruction serialise)
     o->coarse_levels = 0;  // levels below this one run in the cache-free high-occupancy kernel (hash_bwd_coarse_kernel) first
+    o->replicas = 16;      // direct adds of the levels < replica_levels go to this many replicas (power of two); needs `workspace`
+                           // (M-packed 3.67 -> 3.21 ms with 8, 3.16 with 16, 3.18 with 32; M-march and the default configuration +-1 %)
+    o->replica_levels = 4; // 16^3 .. 43^3: 125 568 entries = 1 MB per replica
+    o->workspace = nullptr;
+    o->workspace_bytes = 0;
+}
+
+static int64_t replica_floats(const lse_grid_desc *desc, const lse_hash_bwd_opts &o, int *levels_out)
+{
+    int lv = std::min<int>(o.replica_levels, desc->n_levels);
+    if (o.replicas < 2 || lv <= 0) { if (levels_out) *levels_out = 0; return 0; }
+    if (levels_out) *levels_out = lv;
+    return (int64_t)2 * desc->offsets[lv];        // floats per replica (level offsets are multiples of 8 entries)
+}
+
+extern "C" int64_t lse_hash_bwd_workspace_bytes(const lse_grid_desc *desc, const lse_hash_bwd_opts *opts)
+{
+    if (!desc) return 0;
+    lse_hash_bwd_opts o;
+    lse_hash_bwd_default_opts(&o);
+    if (opts) o = *opts;
+    return replica_floats(desc, o, nullptr) * (int64_t)sizeof(float) * std::max(o.replicas, 0);
 }
 
 extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
@@ -1328,6 +1389,30 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
+    // replicas of the coarsest levels for the direct adds (impl 2's few-runs path and the coarse kernel)
+    float *ws = nullptr;
+    int rep_lv = 0;
+    const int64_t rep_floats = replica_floats(desc, o, &rep_lv);
+    if (o.workspace && rep_floats > 0 && level_begin < rep_lv) {
+        LSE_REQUIRE((o.replicas & (o.replicas - 1)) == 0 && o.replicas <= 64, "lse_hash_bwd: opts.replicas must be a power of two <= 64");
+        LSE_REQUIRE(o.workspace_bytes >= rep_floats * (int64_t)sizeof(float) * o.replicas,
+                    "lse_hash_bwd: workspace of %lld bytes, %lld needed (lse_hash_bwd_workspace_bytes)", (long long)o.workspace_bytes,
+                    (long long)(rep_floats * (int64_t)sizeof(float) * o.replicas));
+        LSE_REQUIRE(((uintptr_t)o.workspace & 15) == 0, "lse_hash_bwd: workspace must be 16-byte aligned");
+        ws = static_cast<float *>(o.workspace);
+        g.rep_levels = rep_lv;
+        g.rep_mask = o.replicas - 1;
+        g.rep_stride = (uint32_t)rep_floats;
+    }
+    struct ReduceAtExit {     // the replicas are folded into dtable after whatever kernels this call launches
+        float *ws, *dtable; int64_t floats; int n_rep; hipStream_t st;
+        ~ReduceAtExit() {
+            if (!ws) return;
+            const uint32_t n4 = (uint32_t)(floats / 4);
+            hipLaunchKernelGGL(hash_bwd_reduce_replicas_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st, ws, dtable, n4, n_rep,
+                               (uint32_t)floats);
+        }
+    } reduce_at_exit{ws, dtable, rep_floats, o.replicas, st};
     // the coarse share of the level range first, in the cache-free kernel; the rest of the range then accumulates into dx
     const int coarse_end = std::min<int>(o.coarse_levels, level_end);
     if (coarse_end > level_begin) {
@@ -1338,9 +1423,9 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         if (dx) hipLaunchKernelGGL((hash_bwd_coarse_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
-                                   dx, n, dbg);
+                                   dx, n, dbg, ws);
         else hipLaunchKernelGGL((hash_bwd_coarse_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
-                                dx, n, dbg);
+                                dx, n, dbg, ws);
         rc = lse::check_launch("lse_hash_bwd (coarse levels)");
         if (rc) return rc;
         if (coarse_end == level_end) return LSE_OK;
@@ -1357,29 +1442,29 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         if (o.gran == 5) {      // the same with 256 slots: half the LDS, three workgroups per CU
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             return lse::check_launch("lse_hash_bwd");
         }
         if (o.gran == 6) {      // gran 4 with the second-generation flush (fewer DS instructions per cache pass)
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             return lse::check_launch("lse_hash_bwd");
         }
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
             return lse::check_launch("lse_hash_bwd");
         }
         if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                   tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                   tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
         else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max);
+                                tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
         return lse::check_launch("lse_hash_bwd");
     }
     if (impl >= 1 && lines_ok) {

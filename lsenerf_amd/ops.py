@@ -9,6 +9,8 @@ from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
 import ctypes
+import time
+
 import torch
 
 from . import _lib
@@ -122,6 +124,7 @@ class MlpMeta:
 # sampler
 # ----------------------------------------------------------------------------------------------------
 MAX_SLOT_ELEMS = 1 << 28   # single-pass marcher: upper limit for R * cap (2 x 1 GiB of scratch)
+SYNC_STATS = {"seconds": 0.0, "count": 0}   # host time spent blocked in the sampler's count read-backs (bench.py reports it)
 
 
 @torch.no_grad()
@@ -154,7 +157,10 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
                       ctypes.c_void_p(flag.data_ptr()), _stream())
             _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
                       ctypes.c_void_p(total.data_ptr()), _stream())
-            n, overflow = (int(v) for v in total.tolist())
+            _t0 = time.perf_counter()
+            n, overflow = (int(v) for v in total.tolist())        # <- host sync #1: the marcher's sample count
+            SYNC_STATS["seconds"] += time.perf_counter() - _t0
+            SYNC_STATS["count"] += 1
             if not overflow:
                 ri = torch.empty(n, dtype=torch.int32, device=dev)
                 ts = torch.empty(n, dtype=torch.float32, device=dev)
@@ -226,7 +232,10 @@ def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early
                   _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
                   ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
     new_packed, total = pack_info_from_counts(new_cnts)
-    m = int(total.item())
+    _t0 = time.perf_counter()
+    m = int(total.item())                                         # <- host sync #2: the survivors of the visibility cull
+    SYNC_STATS["seconds"] += time.perf_counter() - _t0
+    SYNC_STATS["count"] += 1
     o_ri = torch.empty(m, dtype=torch.int32, device=dev)
     o_ts = torch.empty(m, dtype=torch.float32, device=dev)
     o_te = torch.empty(m, dtype=torch.float32, device=dev)
@@ -309,6 +318,23 @@ def _direct_grad(p: torch.Tensor):
     return None
 
 
+_HASH_BWD_WS = {}      # (device index, stream) -> zeroed workspace of the hash backward's coarse-level replicas
+
+
+def hash_bwd_opts_with_workspace(desc: GridDesc, device) -> "_lib.HashBwdOpts":
+    """Default lse_hash_bwd_opts plus the zero-initialised replica workspace the call needs (lse_hash_bwd_workspace_bytes): one
+    buffer per (device, stream), allocated once -- the call returns it zeroed, so it is never cleared from here."""
+    o = _lib.hash_bwd_default_opts()
+    nbytes = int(_lib.load().lse_hash_bwd_workspace_bytes(ctypes.byref(desc), ctypes.byref(o)))
+    if nbytes > 0:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _HASH_BWD_WS.get(key)
+        if ws is None or ws.numel() * 4 < nbytes:
+            ws = _HASH_BWD_WS[key] = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        o.workspace, o.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    return o
+
+
 class _HashFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x01, table, meta: GridMeta, pre_y=None):
@@ -335,18 +361,20 @@ class _HashFn(torch.autograd.Function):
         dtable = direct if direct is not None else torch.zeros_like(table)
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
+        opts = hash_bwd_opts_with_workspace(desc, x01.device)     # defaults + the coarse-level replica workspace
         split = HASH_BWD_SPLIT
         if split is not None and direct is not None and 0 < split[0] < meta.n_levels:
             # fine levels first (most of the table bytes); their gradients are final when the callback runs, so the caller
             # can start exchanging them while the coarse levels are still being computed (dist.OverlappedGradExchange)
             for lo, hi, acc in ((split[0], meta.n_levels, 0), (0, split[0], 1)):
-                _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
-                          ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), acc, lo, hi, n, _stream())
+                _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                          ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), acc, lo, hi, n, ctypes.byref(opts), _stream())
                 if acc == 0:
                     split[1]()
         else:
-            _lib.call("lse_hash_bwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
-                      ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), n, _stream())
+            _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                      ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), 0, 0, meta.n_levels, n, ctypes.byref(opts),
+                      _stream())
         return dx, (None if direct is not None else dtable), None, None
 
 

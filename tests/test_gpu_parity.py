@@ -290,9 +290,15 @@ def _hash_bwd_ex(ops, meta, x, dy, table, with_dx=True, **opt_kw):
     dt = torch.zeros_like(table)
     dx = torch.empty_like(x) if with_dx else None
     desc = meta.desc()
+    # the replica workspace this selection needs (zero on entry; the call must hand it back zeroed)
+    nbytes = int(_lib.load().lse_hash_bwd_workspace_bytes(ctypes.byref(desc), ctypes.byref(o)))
+    ws = torch.zeros(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    if nbytes:
+        o.workspace, o.workspace_bytes = ws.data_ptr(), nbytes
     P = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
     _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x), P(dy), P(table), P(dt), P(dx), 0, 0, meta.n_levels, x.shape[0],
               ctypes.byref(o), ops._stream())
+    assert not bool(ws.any()), "the replica workspace must read zero again after the call"
     return dt, dx
 
 
@@ -326,7 +332,11 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "coarse8_impl1": {"coarse_levels": 8, "impl": 1}, "coarse5_lanes16": {"coarse_levels": 5, "impl": 0},
                 # second-generation flush of the paired sector cache (transposed list, read-and-zero exchange, bulk key reset)
                 "flush2": {"gran": 6}, "flush2_coarse7": {"gran": 6, "coarse_levels": 7}, "flush2_stage_all": {"gran": 6, "stage_max": 64},
-                "flush2_no_few_runs": {"gran": 6, "few_runs": 0, "second_probe": 0}}
+                "flush2_no_few_runs": {"gran": 6, "few_runs": 0, "second_probe": 0},
+                # coarse-level replicas (default: 8 replicas of levels 0-3): off, more of them, every dense level, with the coarse kernel
+                "no_replicas": {"replicas": 0}, "replicas8": {"replicas": 8}, "replicas32_levels6": {"replicas": 32, "replica_levels": 6},
+                "replicas_coarse_kernel": {"coarse_levels": 7, "replicas": 16, "replica_levels": 5},
+                "replicas_few_runs16": {"few_runs": 16, "replica_levels": 16, "replicas": 4}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
     for sc in meta.scales:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
-    assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts"} == set(names)
+    assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts", "lse_hash_bwd_workspace_bytes"} == set(names)
     assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 3
 
 

@@ -56,6 +56,10 @@ for name, x01 in regimes.items():
                 nodx = bool(int(val))
             else:
                 setattr(o, k, int(val))
+        nb = int(_lib.load().lse_hash_bwd_workspace_bytes(ctypes.byref(desc), ctypes.byref(o)))
+        if nb:      # the product path's replica workspace (ops.hash_bwd_opts_with_workspace)
+            o._ws = torch.zeros(nb // 4, dtype=torch.float32, device=dev)
+            o.workspace, o.workspace_bytes = o._ws.data_ptr(), nb
         fns.append((v, (o, nodx)))
     times = {v: [] for v, _ in fns}
     for rnd in range(6):
