@@ -226,6 +226,16 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
 int lse_set_option(const char *name, int64_t value);
 int lse_get_option(const char *name, int64_t *value);
 
+/* Device-side sample count.  The sampler knows the number of packed samples only on the device (lse_pack_info_from_counts);
+ * reading it back costs a host synchronisation per sampler call, twice per step with the visibility pre-pass.  With a non-NULL
+ * pointer set here (per calling thread, until reset with NULL), the PER-SAMPLE entry points
+ *     lse_positions_fwd / _bwd, lse_hash_fwd, lse_hash_bwd / _levels / _ex (impl 2), lse_mlp_fwd / _bwd
+ * treat their `n` argument as a CAPACITY -- buffer extents, level strides and the launch grid are sized by it -- and every kernel
+ * clamps it to the int64 the pointer addresses when it starts; workgroups past the count leave at once.  Nothing at or beyond
+ * the count is read or written.  The per-ray entry points (visibility, compaction, volume rendering, ray reductions) take
+ * their counts from packed_info and need nothing.  lse_density_fwd / _bwd and the unfused lse_mlp_wgrad reject a set pointer. */
+int lse_set_device_count(const int64_t *n_dev);
+
 /* fused MLP forward on the matrix cores (f32 MFMA, or bf16 MFMA on three-piece operands with the same error bound: option
  * "mlp_fwd_impl").  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major

@@ -66,6 +66,7 @@ SIGNATURES = {
     "lse_hash_bwd_levels": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P],
     "lse_hash_bwd_ex": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, POINTER(HashBwdOpts), P],
     "lse_set_option": [c_char_p, I64],
+    "lse_set_device_count": [P],
     "lse_get_option": [c_char_p, POINTER(c_int64)],
     "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
     "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, P, I64, P],

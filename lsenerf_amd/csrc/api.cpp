@@ -29,6 +29,9 @@ static Option g_options[] = {
     {"traverse_vec", {1}},
     {"traverse_fma", {0}},
 };
+static thread_local const int64_t *g_device_count = nullptr;
+const int64_t *device_count() { return g_device_count; }
+
 int64_t option(const char *name)
 {
     for (auto &o : g_options)
@@ -47,6 +50,12 @@ extern "C" int lse_set_option(const char *name, int64_t value)
         }
     lse::set_error("lse_set_option: unknown option '%s'", name);
     return LSE_E_INVALID;
+}
+
+extern "C" int lse_set_device_count(const int64_t *n_dev)
+{
+    lse::g_device_count = n_dev;
+    return LSE_OK;
 }
 
 extern "C" int lse_get_option(const char *name, int64_t *value)

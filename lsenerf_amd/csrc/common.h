@@ -11,6 +11,9 @@ namespace lse {
 
 void set_error(const char *fmt, ...);
 int64_t option(const char *name);   // run-time development knob (lse_set_option), 0 for unknown names
+// lse_set_device_count: when non-null, the per-sample entry points hand this pointer to their kernels, which clamp the
+// host-side sample count (a CAPACITY then) to the int64 it points to -- the count never has to visit the host
+const int64_t *device_count();
 
 static inline hipStream_t as_stream(lse_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -33,6 +36,13 @@ static inline int check_launch(const char *what)
     } while (0)
 
 constexpr int kWave = 64;
+
+__device__ __forceinline__ int64_t clamp_count(int64_t n, const int64_t *n_dev)
+{
+    if (n_dev == nullptr) return n;
+    const int64_t m = *n_dev;
+    return m < n ? (m < 0 ? 0 : m) : n;
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

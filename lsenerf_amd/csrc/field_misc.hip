@@ -31,10 +31,11 @@ __device__ __forceinline__ void sample_pos(const float *__restrict__ o, const fl
 __global__ __launch_bounds__(256) void positions_fwd_kernel(const float *__restrict__ o, const float *__restrict__ d,
                                                             const int32_t *__restrict__ ri, const float *__restrict__ ts,
                                                             const float *__restrict__ te, int64_t n, int contraction,
-                                                            Box box, float *__restrict__ x01, uint8_t *__restrict__ sel)
+                                                            Box box, float *__restrict__ x01, uint8_t *__restrict__ sel,
+                                                            const int64_t *__restrict__ n_dev)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= lse::clamp_count(n, n_dev)) return;
     float p[3], t2;
     sample_pos(o, d, ri, ts, te, i, p, t2);
     float x[3];
@@ -59,10 +60,10 @@ __global__ __launch_bounds__(256) void positions_bwd_kernel(const float *__restr
                                                             const int32_t *__restrict__ ri, const float *__restrict__ ts,
                                                             const float *__restrict__ te, int64_t n, int contraction,
                                                             Box box, const float *__restrict__ dx01,
-                                                            float *__restrict__ dpos)
+                                                            float *__restrict__ dpos, const int64_t *__restrict__ n_dev)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= lse::clamp_count(n, n_dev)) return;
     float p[3], t2;
     sample_pos(o, d, ri, ts, te, i, p, t2);
     float g[3] = {dx01[i * 3 + 0], dx01[i * 3 + 1], dx01[i * 3 + 2]};
@@ -383,7 +384,8 @@ extern "C" int lse_positions_fwd(const float *rays_o, const float *rays_d, const
     LSE_REQUIRE(!ray_idx || (rays_d && t_starts && t_ends), "lse_positions_fwd: ray mode needs rays_d, t_starts, t_ends");
     LSE_REQUIRE(contraction || h_aabb, "lse_positions_fwd: aabb normalisation needs h_aabb");
     hipLaunchKernelGGL(positions_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream),
-                       rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), x01, selector);
+                       rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), x01, selector,
+                       lse::device_count());
     return lse::check_launch("lse_positions_fwd");
 }
 
@@ -397,7 +399,8 @@ extern "C" int lse_positions_bwd(const float *rays_o, const float *rays_d, const
     LSE_REQUIRE(!ray_idx || (rays_d && t_starts && t_ends), "lse_positions_bwd: ray mode needs rays_d, t_starts, t_ends");
     LSE_REQUIRE(contraction || h_aabb, "lse_positions_bwd: aabb normalisation needs h_aabb");
     hipLaunchKernelGGL(positions_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream),
-                       rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), d_x01, d_pos);
+                       rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), d_x01, d_pos,
+                       lse::device_count());
     return lse::check_launch("lse_positions_bwd");
 }
 
@@ -417,6 +420,7 @@ extern "C" int lse_density_fwd(const float *h, const uint8_t *selector, float sc
                                lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_density_fwd: n < 0");
+    LSE_REQUIRE(!lse::device_count(), "lse_density_fwd does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(h && sigma, "lse_density_fwd: null pointer");
     hipLaunchKernelGGL(density_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream), h,
@@ -428,6 +432,7 @@ extern "C" int lse_density_bwd(const float *h, const uint8_t *selector, float sc
                                int64_t n, lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_density_bwd: n < 0");
+    LSE_REQUIRE(!lse::device_count(), "lse_density_bwd does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(h && d_sigma && d_h, "lse_density_bwd: null pointer");
     hipLaunchKernelGGL(density_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream), h,

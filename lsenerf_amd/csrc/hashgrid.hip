@@ -117,9 +117,12 @@ constexpr int kFwdItems = LSE_FWD_ITEMS;   // samples per lane -> 32 independent
 
 __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, const float *__restrict__ x,
                                                                const float2 *__restrict__ table,
-                                                               float2 *__restrict__ y, int64_t n, int64_t chunks,
-                                                               int mapping)
+                                                               float2 *__restrict__ y, int64_t n_cap, int64_t chunks,
+                                                               int mapping, const int64_t *__restrict__ n_dev)
 {
+    // n_cap: the level stride of y and the sample capacity the grid was sized for; n: the samples that exist (device-side
+    // count when one is set: workgroups past it leave at once)
+    const int64_t n = lse::clamp_count(n_cap, n_dev);
     const int L = g.n_levels;
     int level;
     int64_t chunk;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
     const LevelInfo li = level_info(g, level);
     const float2 *__restrict__ tab = table + li.offset;
     const int64_t base = chunk * (int64_t)(kFwdThreads * kFwdItems) + threadIdx.x;
+    if (chunk * (int64_t)(kFwdThreads * kFwdItems) >= n) return;
 
     float w[kFwdItems][3];
     uint32_t p[kFwdItems][3];
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
             r.y = fmaf(wt, v[it][c].y, r.y);
         }
         const int64_t i = base + (int64_t)it * kFwdThreads;
-        if (valid[it]) y[(int64_t)level * n + i] = r;
+        if (valid[it]) y[(int64_t)level * n_cap + i] = r;
     }
 }
 
@@ -718,9 +722,10 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg, int few_runs, int second_probe, int stage_max,
-                                                              float *__restrict__ ws)
+                                                              int64_t n_cap, int dbg, int few_runs, int second_probe, int stage_max,
+                                                              float *__restrict__ ws, const int64_t *__restrict__ n_dev)
 {
+    const int64_t n = lse::clamp_count(n_cap, n_dev);      // n_cap stays the level stride of dy
     constexpr int kRounds = 1;                 // one 64-sample round per wave
     constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
     constexpr int kPay = 2 * kEnt;             // payload floats per slot = lanes per slot in the flush
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             pos_fract(px[r][0], li.scale, w0, p0);
             pos_fract(px[r][1], li.scale, w1, p1);
             pos_fract(px[r][2], li.scale, w2, p2);
-            float2 gy = dy[(int64_t)l * n + si[r]];
+            float2 gy = dy[(int64_t)l * n_cap + si[r]];
             if (!valid[r]) gy = make_float2(0.f, 0.f);
             uint32_t idx[8];
             corner_indices(li, p0, p1, p2, idx);
@@ -1133,8 +1138,10 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
-                                                              int64_t n, int dbg, float *__restrict__ ws)
+                                                              int64_t n_cap, int dbg, float *__restrict__ ws,
+                                                              const int64_t *__restrict__ n_dev)
 {
+    const int64_t n = lse::clamp_count(n_cap, n_dev);      // n_cap stays the level stride of dy
     constexpr int kBatch = 16;                      // run ends per staging trip
     __shared__ uint32_t s_stage[4][kBatch * 24];    // [run][8 idx | 16 sums]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1159,7 +1166,7 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
         pos_fract(px0, li.scale, w0, p0);
         pos_fract(px1, li.scale, w1, p1);
         pos_fract(px2, li.scale, w2, p2);
-        float2 gy = dy[(int64_t)l * n + si];
+        float2 gy = dy[(int64_t)l * n_cap + si];
         if (!valid) gy = make_float2(0.f, 0.f);
         uint32_t idx[8];
         corner_indices(li, p0, p1, p2, idx);
@@ -1304,7 +1311,8 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
     const int mapping = (int)lse::option("hash_fwd_mapping");
     hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, lse::as_stream(stream), g, x01,
-                       reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping);
+                       reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping,
+                       lse::device_count());
     return lse::check_launch("lse_hash_fwd");
 }
 
@@ -1389,6 +1397,9 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
+    // device-side sample count (lse_set_device_count): honoured by the default kernel and the coarse kernel
+    const int64_t *n_dev = lse::device_count();
+    LSE_REQUIRE(!n_dev || (impl == 2), "lse_hash_bwd: a device-side count needs opts.impl == 2");
     // replicas of the coarsest levels for the direct adds (impl 2's few-runs path and the coarse kernel)
     float *ws = nullptr;
     int rep_lv = 0;
@@ -1423,9 +1434,9 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         if (dx) hipLaunchKernelGGL((hash_bwd_coarse_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
-                                   dx, n, dbg, ws);
+                                   dx, n, dbg, ws, n_dev);
         else hipLaunchKernelGGL((hash_bwd_coarse_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, gc, x01, dy2, tb2, dtable,
-                                dx, n, dbg, ws);
+                                dx, n, dbg, ws, n_dev);
         rc = lse::check_launch("lse_hash_bwd (coarse levels)");
         if (rc) return rc;
         if (coarse_end == level_end) return LSE_OK;
@@ -1435,6 +1446,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
     bool lines_ok = true;
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
+    LSE_REQUIRE(!n_dev || lines_ok, "lse_hash_bwd: a device-side count needs 64-byte aligned levels (the default kernel)");
     if (impl == 2 && lines_ok) {     // per-wave sector cache with run ends of several levels batched into one pass
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
@@ -1442,29 +1454,29 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         if (o.gran == 5) {      // the same with 256 slots: half the LDS, three workgroups per CU
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
         if (o.gran == 6) {      // gran 4 with the second-generation flush (fewer DS instructions per cache pass)
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
         if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                   tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                   tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
         else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws);
+                                tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
         return lse::check_launch("lse_hash_bwd");
     }
     if (impl >= 1 && lines_ok) {

@@ -41,7 +41,9 @@ struct MlpArgs {
     const int32_t *row_bias_idx;
     float *out;
     float *act;
-    int64_t n;
+    int64_t n;                   // samples (a capacity when n_dev is set: every kernel clamps it first)
+    const int64_t *n_dev;        // lse_set_device_count
+    int64_t n_stride;            // the host-side n: level stride of level-major inputs / gradients, layer stride of row-major activations
     int out_activation;
     // backward
     const float *d_out;
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    const int64_t n = a.n;
+    a.n = lse::clamp_count(a.n, a.n_dev);
+    const int64_t n = a.n, ns = a.n_stride;
     constexpr int TS = 16 * CT;   // samples per wave tile
     const int64_t n_tiles = (n + TS - 1) / TS;
     const int64_t tile_stride = (int64_t)gridDim.x * NW;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void mlp_fwd_kernel(Mlp
             if (INL == LSE_IN_LEVELMAJOR) {
 #pragma unroll
                 for (int m = 0; m < KIN / 8; ++m) {
-                    const float2 v = reinterpret_cast<const float2 *>(a.in)[(int64_t)(4 * m + q) * n + s[ct]];
+                    const float2 v = reinterpret_cast<const float2 *>(a.in)[(int64_t)(4 * m + q) * ns + s[ct]];
                     breg[ct][2 * m] = v.x;
                     breg[ct][2 * m + 1] = v.y;
                 }
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(512) void mlp_fwd2_kernel(MlpArgs a, bool nt)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    const int64_t n = a.n;
+    a.n = lse::clamp_count(a.n, a.n_dev);
+    const int64_t n = a.n, ns = a.n_stride;
     const int64_t n_tiles = (n + TS - 1) / TS;
     const int64_t total_waves = (int64_t)gridDim.x * NW;
     const int64_t per = (n_tiles + total_waves - 1) / total_waves;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(512) void mlp_fwd2_kernel(MlpArgs a, bool nt)
                 const float2 *in2 = reinterpret_cast<const float2 *>(a.in) + tile_base;
 #pragma unroll
                 for (int m = 0; m < KIN / 8; ++m) {
-                    const float2 v = in2[(int64_t)(4 * m + q) * n + slc];
+                    const float2 v = in2[(int64_t)(4 * m + q) * ns + slc];
                     breg[ct][2 * m] = v.x;
                     breg[ct][2 * m + 1] = v.y;
                 }
@@ -661,11 +665,12 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
 #pragma unroll
             for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const int64_t n = a.n;
+    a.n = lse::clamp_count(a.n, a.n_dev);
+    const int64_t n = a.n, ns = a.n_stride;
     constexpr int TS = 16 * CT;   // samples per wave tile
     const int64_t n_tiles = (n + TS - 1) / TS;
     const float *act_last = a.act + (int64_t)(NHL - 1) * a.act_layer_stride;
-    float *dact_last = a.d_act ? a.d_act + (int64_t)(NHL - 1) * n * WIDTH : nullptr;
+    float *dact_last = a.d_act ? a.d_act + (int64_t)(NHL - 1) * ns * WIDTH : nullptr;
     // One tile ahead: the raw operands of the NEXT tile (output gradient, saved last-layer activations, the output
     // values the activation / density backward needs) are requested before the current tile's MFMA work starts -- the
     // fused-wgrad kernel runs one wave per SIMD, so nothing else would hide that latency.
@@ -846,8 +851,8 @@ __global__ __launch_bounds__(64 * NW, ((NW == 4 && !WGRAD) ? 2 : 1)) void mlp_bw
                         if (16 * rb + 4 * q < KIN) {
                             float2 *d2 = reinterpret_cast<float2 *>(a.d_in);
                             const int lv = 8 * rb + 2 * q;
-                            d2[(int64_t)lv * n + s[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
-                            d2[(int64_t)(lv + 1) * n + s[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
+                            d2[(int64_t)lv * ns + s[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
+                            d2[(int64_t)(lv + 1) * ns + s[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
                         }
                     } else {
                         if (16 * rb + 4 * q < KIN)
@@ -935,7 +940,8 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t n = a.n;
+    a.n = lse::clamp_count(a.n, a.n_dev);
+    const int64_t n = a.n, ns = a.n_stride;
     const int64_t n_tiles = (n + TS - 1) / TS;
     const int64_t total_waves = (int64_t)gridDim.x * NW;
     const int64_t per = (n_tiles + total_waves - 1) / total_waves;
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                     const int col = 16 * kb + j;
                     float v = 0.f;
                     if (col < KIN) {
-                        if (INL == LSE_IN_LEVELMAJOR) v = in_t[((int64_t)(col >> 1) * n + srow) * 2 + (col & 1)];
+                        if (INL == LSE_IN_LEVELMAJOR) v = in_t[((int64_t)(col >> 1) * ns + srow) * 2 + (col & 1)];
                         else v = in_t[(unsigned)(srow * KIN + col)];
                     }
                     gb[kb][t] = v;
@@ -1238,8 +1244,8 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd2_kernel(MlpArgs a)
                     if (INL == LSE_IN_LEVELMAJOR) {
                         float2 *d2 = reinterpret_cast<float2 *>(a.d_in) + tile_base;
                         const int lv = 8 * rb + 2 * q;
-                        d2[(int64_t)lv * n + sl[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
-                        d2[(int64_t)(lv + 1) * n + sl[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
+                        d2[(int64_t)lv * ns + sl[ct]] = make_float2(di[rb][ct][0], di[rb][ct][1]);
+                        d2[(int64_t)(lv + 1) * ns + sl[ct]] = make_float2(di[rb][ct][2], di[rb][ct][3]);
                     } else {
                         *reinterpret_cast<f32x4 *>(a.d_in + tile_base * KIN + (unsigned)(sl[ct] * KIN + 16 * rb + 4 * q)) = di[rb][ct];
                     }
@@ -1640,7 +1646,8 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     MlpArgs a{};
     LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_fwd: out_cols must be 16 or 4");
     a.params = params; a.in = in; a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.out = out; a.act = act;
-    a.n = n; a.out_activation = desc->out_activation; a.out_cols = out_cols; a.sigma_out = sigma_out;
+    a.n = n; a.n_stride = n; a.n_dev = lse::device_count();
+    a.out_activation = desc->out_activation; a.out_cols = out_cols; a.sigma_out = sigma_out;
     a.selector = selector; a.density_scale = density_scale;
     a.act_tiled = act_tiled;
     a.act_layer_stride = act_tiled ? ((n + 15) / 16 * 16) * (int64_t)desc->width : n * (int64_t)desc->width;
@@ -1670,6 +1677,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
     a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_act0 = d_act0; a.d_in = d_in; a.d_params = d_params; a.n = n;
+    a.n_stride = n; a.n_dev = lse::device_count();
     a.out_activation = desc->out_activation; a.out_cols = out_cols; a.d_sigma = d_sigma; a.selector = selector;
     a.density_scale = density_scale;
     a.act_tiled = act_tiled;
@@ -1696,6 +1704,7 @@ extern "C" int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const fl
     int rc = check_desc(desc, "lse_mlp_wgrad");
     if (rc) return rc;
     LSE_REQUIRE(n >= 0, "lse_mlp_wgrad: n < 0");
+    LSE_REQUIRE(!lse::device_count(), "lse_mlp_wgrad does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(in && act && d_act && d_out_pre && d_params, "lse_mlp_wgrad: null pointer");
     LSE_REQUIRE((desc->w0_ld == 0 || desc->w0_ld == desc->n_in) && !desc->w0_mask_col0,

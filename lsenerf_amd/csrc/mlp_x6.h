@@ -251,7 +251,7 @@ __device__ __forceinline__ void load_in_x6(const MlpArgs &a, int64_t tile, int j
             const float2 *in2 = reinterpret_cast<const float2 *>(a.in) + tile_base;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const float2 u = in2[(int64_t)(4 * q + 2 * m) * n + slc], v = in2[(int64_t)(4 * q + 2 * m + 1) * n + slc];
+                const float2 u = in2[(int64_t)(4 * q + 2 * m) * a.n_stride + slc], v = in2[(int64_t)(4 * q + 2 * m + 1) * a.n_stride + slc];
                 raw[ct][m] = (f32x4){u.x, u.y, v.x, v.y};
             }
         } else {
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    a.n = lse::clamp_count(a.n, a.n_dev);
     const int64_t n = a.n;
     const int64_t n_tiles = (n + TS - 1) / TS;
     const int64_t total_waves = (int64_t)gridDim.x * NW;
@@ -607,7 +608,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) acc0[mb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t n = a.n;
+    a.n = lse::clamp_count(a.n, a.n_dev);
+    const int64_t n = a.n, ns = a.n_stride;
     const int64_t n_tiles = (n + TS - 1) / TS;
     const int64_t total_waves = (int64_t)gridDim.x * NW;
     const int64_t per = (n_tiles + total_waves - 1) / total_waves;
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                 for (int t = 0; t < 4 * CT; ++t) {
                     int s_t = 16 * (t >> 2) + 4 * q + (t & 3);
                     s_t = s_t < n_rem ? s_t : n_rem - 1;
-                    if (INL == LSE_IN_LEVELMAJOR) vin[nb][t] = a.in[((int64_t)(col >> 1) * n + tile_base + s_t) * 2 + (col & 1)];
+                    if (INL == LSE_IN_LEVELMAJOR) vin[nb][t] = a.in[((int64_t)(col >> 1) * ns + tile_base + s_t) * 2 + (col & 1)];
                     else vin[nb][t] = a.in[(tile_base + s_t) * KIN + col];
                 }
             }
@@ -1224,8 +1226,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                     if (INL == LSE_IN_LEVELMAJOR) {
                         float2 *d2 = reinterpret_cast<float2 *>(a.d_in) + tile_base;
                         const int lv = 8 * cb + 2 * q;
-                        d2[(int64_t)lv * n + sl[ct]] = make_float2(di[ct][0], di[ct][1]);
-                        d2[(int64_t)(lv + 1) * n + sl[ct]] = make_float2(di[ct][2], di[ct][3]);
+                        d2[(int64_t)lv * ns + sl[ct]] = make_float2(di[ct][0], di[ct][1]);
+                        d2[(int64_t)(lv + 1) * ns + sl[ct]] = make_float2(di[ct][2], di[ct][3]);
                     } else {
                         *reinterpret_cast<f32x4 *>(a.d_in + tile_base * KIN + (unsigned)(sl[ct] * KIN + 16 * cb + 4 * q)) = di[ct];
                     }

@@ -59,8 +59,8 @@ class Ed_HashEncoding(nn.Module):
     def get_out_dim(self) -> int:
         return self.num_levels * self.features_per_level
 
-    def forward_levelmajor(self, in_tensor: Tensor) -> Tensor:
-        return ops.hash_encode(in_tensor, self.params, self.meta)
+    def forward_levelmajor(self, in_tensor: Tensor, n_dev: Optional[Tensor] = None) -> Tensor:
+        return ops.hash_encode(in_tensor, self.params, self.meta, n_dev=n_dev)
 
     def forward(self, in_tensor: Tensor) -> Tensor:
         y = self.forward_levelmajor(in_tensor.reshape(-1, 3).contiguous())
@@ -309,10 +309,10 @@ class LSEField(nn.Module):
             self._aabb6 = [float(v) for v in self.aabb.flatten().tolist()]
         return self._aabb6
 
-    def _x01(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info):
+    def _x01(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, n_dev=None):
         contraction = self._contraction == "inf"
         return ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction,
-                             None if contraction else self._aabb_list())
+                             None if contraction else self._aabb_list(), n_dev=n_dev)
 
     def prepass_sigma_fn(self, origins: Tensor, directions: Tensor) -> Callable:
         """``sigma_fn`` of the sampler's visibility pre-pass (nerfstudio VolumetricSampler.get_sigma_fn) on packed samples.
@@ -323,12 +323,13 @@ class LSEField(nn.Module):
         fld = self
         state = {}
 
-        def sigma_fn(t_starts, t_ends, ray_indices):
+        def sigma_fn(t_starts, t_ends, ray_indices, n_dev=None):
+            """``n_dev``: device-side count of the candidates (deferred sampling: the arrays then have capacity extent)."""
             ri = ray_indices if ray_indices.dtype == torch.int32 else ray_indices.to(torch.int32)
             with torch.no_grad():
-                x01, sel = fld._x01(origins, directions, ri, t_starts, t_ends, None)
-                y = fld.mlp_base_grid.forward_levelmajor(x01)
-                sigma = fld._base_mlp(y, sel, x01.shape[0])[1]
+                x01, sel = fld._x01(origins, directions, ri, t_starts, t_ends, None, n_dev)
+                y = fld.mlp_base_grid.forward_levelmajor(x01, n_dev)
+                sigma = fld._base_mlp(y, sel, x01.shape[0], n_dev)[1]
             state.update(x01=x01, sel=sel, y=y)
             return sigma
 
@@ -347,12 +348,14 @@ class LSEField(nn.Module):
         sigma_fn.on_cull = on_cull
         return sigma_fn
 
-    def _base_mlp(self, y: Tensor, sel: Tensor, n: int):
+    def _base_mlp(self, y: Tensor, sel: Tensor, n: int, n_dev: Optional[Tensor] = None):
         """(h[N,16], sigma[N]) = base MLP on level-major hash features with the fused trunc_exp density head."""
         mlp = self.mlp_base_mlp
         dens = (sel, self.average_init_density)    # trunc_exp density head fused into the MLP epilogue / backward
         if mlp.in_pad == mlp.in_dim:
-            return ops.fused_mlp(mlp.params, y, mlp.meta(), n, density=dens)
+            return ops.fused_mlp(mlp.params, y, mlp.meta(), n, density=dens, n_dev=n_dev)
+        if n_dev is not None:
+            raise _lib.LseHipError("a device-side sample count needs the 32-input base MLP (L * F == 32)")
         # small grids (L*F < 16): tcnn's ones-padding columns act as a bias shared by every sample
         kparams, bias = mlp.split_padding()
         idx = torch.zeros(n, dtype=torch.int32, device=y.device)
@@ -369,23 +372,25 @@ class LSEField(nn.Module):
             return None
         return pp
 
-    def density_packed(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info
+    def density_packed(self, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, n_dev: Optional[Tensor] = None
                        ) -> Tuple[Tensor, Tensor, Tensor]:
-        """Fast path of get_density on packed samples: returns (sigma[N], h[N,16] base-MLP output, selector[N])."""
+        """Fast path of get_density on packed samples: returns (sigma[N], h[N,16] base-MLP output, selector[N]).
+        ``n_dev``: device-side sample count (int64 [1]) when the arrays have capacity extent (deferred sampling)."""
         pp = self._take_prepass(rays_o, rays_d, ray_idx, t_starts) if t_starts is not None else None
         if pp is not None:   # survivors of this step's visibility pre-pass: positions + hash features are already there
             x01, sel = ops.positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, self._contraction == "inf",
-                                     None if self._contraction == "inf" else self._aabb_list(), precomputed=(pp["x01"], pp["sel"]))
-            y = ops.hash_encode(x01, self.mlp_base_grid.params, self.mlp_base_grid.meta, precomputed=pp["y"])
-            h, sigma = self._base_mlp(y, sel, x01.shape[0])
+                                     None if self._contraction == "inf" else self._aabb_list(), precomputed=(pp["x01"], pp["sel"]),
+                                     n_dev=n_dev)
+            y = ops.hash_encode(x01, self.mlp_base_grid.params, self.mlp_base_grid.meta, precomputed=pp["y"], n_dev=n_dev)
+            h, sigma = self._base_mlp(y, sel, x01.shape[0], n_dev)
             return sigma, h, sel
-        x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
-        y = self.mlp_base_grid.forward_levelmajor(x01)
-        h, sigma = self._base_mlp(y, sel, x01.shape[0])
+        x01, sel = self._x01(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, n_dev)
+        y = self.mlp_base_grid.forward_levelmajor(x01, n_dev)
+        h, sigma = self._base_mlp(y, sel, x01.shape[0], n_dev)
         return sigma, h, sel
 
     def rgb_packed(self, h: Tensor, rays_d: Tensor, emb_idx: Optional[Tensor], ray_idx: Optional[Tensor],
-                   packed_info: Optional[Tensor], emb_table: Optional[Tensor]) -> Tensor:
+                   packed_info: Optional[Tensor], emb_table: Optional[Tensor], n_dev: Optional[Tensor] = None) -> Tensor:
         """Fast path of get_outputs: h[N,16] from ``density_packed``; per-ray directions/embedding ids.
         Returns the compact head output [N,4] (columns 0..2 = RGB).
 
@@ -404,7 +409,7 @@ class LSEField(nn.Module):
         row_bias = ops.ray_bias(rays_d, emb_table, emb_idx, head.params, head.layer_width)        # [R, W]
         meta = ops.MlpMeta(16, head.layer_width, head.n_hidden_layers, head.out_act, _lib.LSE_IN_ROWMAJOR,
                            w0_ld=head.in_pad, w0_col=15, w0_mask_col0=1)
-        return ops.fused_mlp(head.params, h, meta, n, row_bias, ray_idx, packed_info, out_cols=4)
+        return ops.fused_mlp(head.params, h, meta, n, row_bias, ray_idx, packed_info, out_cols=4, n_dev=n_dev)
 
     def _train_emb_table(self):
         if self.embedding_appearance is None:

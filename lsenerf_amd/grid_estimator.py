@@ -71,13 +71,49 @@ class LSEOccGridEstimator(nn.Module):
             self._diag_cache = (ver, float((box[3:] - box[:3]).norm()))
         return max(0.0, min(self._diag_cache[1], float(far_plane) - float(near_plane))) + 1e-3 * self._diag_cache[1]
 
+    def _cap_per_ray(self, near_plane: float, far_plane: float, step: float, cone: float) -> int:
+        """Host-side PROVEN upper bound of the samples one ray can yield.  The marcher's cursor only moves forward, by
+        dt(t) = clamp(t * cone, step, 1e10) per step -- through occupied cells (a sample each) and empty ones alike -- from the
+        near plane to at most ``near + span`` (span: diagonal of the outermost box, clipped by the planes).  Below
+        t_c = step / cone every step is ``step`` long; above, t grows by the factor 1 + cone per step.  A few steps of slack
+        cover the re-alignments at interval boundaries."""
+        assert step > 0, "deferred sampling needs a positive step size"
+        t0 = max(float(near_plane), 0.0)
+        t1 = t0 + self._max_span(near_plane, far_plane)
+        if cone <= 0.0:
+            n = (t1 - t0) / step
+        else:
+            import math
+            tc = step / cone
+            n = max(0.0, min(tc, t1) - t0) / step
+            if t1 > tc:
+                n += math.log(t1 / max(tc, t0, 1e-30)) / math.log1p(cone)
+        return int(n) + 16 + 4 * self.levels
+
+    def check_deferred_overflow(self) -> None:
+        """Deferred sampling never reads the marcher's slot-overflow flag on the critical path (the capacity is a proven
+        bound); this reads the flags of the calls made so far -- one host synchronisation -- and raises if one is set."""
+        flags, self._deferred_flags = getattr(self, "_deferred_flags", []), []
+        if flags and bool(torch.stack([f.reshape(()) for f in flags]).any().item()):
+            raise RuntimeError("deferred sampling: a ray produced more samples than LSEOccGridEstimator._cap_per_ray allows")
+
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
                  t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
-                 cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False):
+                 cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False,
+                 deferred: bool = False):
         """Sampling with spatial skipping (not differentiable).  Returns (ray_indices, t_starts, t_ends); with
-        ``return_packed`` also ``packed_info`` and ray_indices stays int32."""
+        ``return_packed`` also ``packed_info`` and ray_indices stays int32.
+
+        ``deferred``: no host read-back of the sample counts (the reference's path synchronises four times here, the
+        default path of this class once per stage).  Returns (ray_indices, t_starts, t_ends, packed_info, n_dev): the packed
+        arrays have CAPACITY extent ``R * _cap_per_ray(...)``, ``n_dev`` (int64 [1], on the device) holds the number of valid
+        leading entries, and every per-sample kernel downstream is handed ``n_dev`` (ops._call_n).  Values are those of the
+        default path bit for bit; only the extents of the arrays differ."""
+        if deferred:
+            return self._sampling_deferred(rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max,
+                                           render_step_size, early_stop_eps, alpha_thre, stratified, cone_angle, jitter)
         # near / far planes clamped by t_min / t_max, stratified start offset u * step (one launch, bit-identical to the
         # reference's full_like / clamp / rand_like-multiply-add sequence)
         u = None
@@ -118,6 +154,46 @@ class LSEOccGridEstimator(nn.Module):
         if return_packed:
             return ray_indices, t_starts, t_ends, packed_info
         return ray_indices.long(), t_starts, t_ends
+
+    def _sampling_deferred(self, rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
+                           early_stop_eps, alpha_thre, stratified, cone_angle, jitter):
+        u = None
+        if stratified:
+            u = jitter if jitter is not None else torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device)
+        near_planes, far_planes = ops.ray_planes(rays_o.shape[0], rays_o.device, near_plane, far_plane, t_min, t_max, u,
+                                                 render_step_size)
+        cap = self._cap_per_ray(near_plane, far_plane, render_step_size, cone_angle)
+        ray_indices, t_starts, t_ends, packed_info, n_dev, overflow = ops.traverse_grids_deferred(
+            rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
+            render_step_size, cone_angle, cap)
+        flags = self.__dict__.setdefault("_deferred_flags", [])
+        flags.append(overflow)
+        if len(flags) > 4096:
+            del flags[:2048]
+        if self.after_march_hook is not None:
+            self.after_march_hook()
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
+            if self._occ_mean_host is None:
+                self._occ_mean_host = self.occs.mean().item()     # (after a grid refresh only: not on the per-step path)
+            alpha_thre = min(alpha_thre, self._occ_mean_host)
+            with torch.no_grad():
+                if sigma_fn is not None:
+                    try:
+                        vals = sigma_fn(t_starts, t_ends, ray_indices, n_dev=n_dev)
+                    except TypeError as e:
+                        raise TypeError("deferred sampling needs a sigma_fn that accepts the device-side count (n_dev=...): "
+                                        "LSEField.prepass_sigma_fn does") from e
+                else:
+                    vals = alpha_fn(t_starts, t_ends, ray_indices)
+            assert vals.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(vals.shape)
+            old_packed = packed_info
+            ray_indices, t_starts, t_ends, packed_info, mask, n_dev = ops.visibility_compact_deferred(
+                ray_indices, t_starts, t_ends, vals.contiguous(), packed_info, early_stop_eps, alpha_thre,
+                from_alpha=sigma_fn is None)
+            on_cull = getattr(sigma_fn, "on_cull", None) if sigma_fn is not None else None
+            if on_cull is not None:
+                on_cull(mask, old_packed, packed_info, ray_indices, t_starts, t_ends)
+        return ray_indices, t_starts, t_ends, packed_info, n_dev
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -263,6 +263,21 @@ class VolumetricSampler(nn.Module):
             return density_fn(positions, times[ri]).squeeze(-1)
         return sigma_fn
 
+    def sample_packed(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
+                      alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None):
+        """The sampler call of ``forward`` for the packed fast path, WITHOUT reading a sample count back to the host and without
+        building per-sample ``RaySamples`` (gathered origins / directions / camera indices): returns (ray_indices int32,
+        t_starts, t_ends, packed_info, n_dev) with capacity-extent arrays (LSEOccGridEstimator.sampling(deferred=True))."""
+        rays_o = ray_bundle.origins.contiguous()
+        rays_d = ray_bundle.directions.contiguous()
+        t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None else None
+        t_max = ray_bundle.fars.contiguous().reshape(-1) if ray_bundle.fars is not None else None
+        return self.occupancy_grid.sampling(
+            rays_o=rays_o.detach(), rays_d=rays_d.detach(), t_min=t_min, t_max=t_max,
+            sigma_fn=self.get_sigma_fn(rays_o.detach(), rays_d.detach(), ray_bundle.times),
+            render_step_size=render_step_size, near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane,
+            stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, deferred=True)
+
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
                 alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None
                 ) -> Tuple[RaySamples, Tensor]:
@@ -313,6 +328,10 @@ class LSENeRFModel(nn.Module):
         self.num_train_data = num_train_data
         self.kwargs = kwargs
         self.collider = None                       # enable_collider False for NGP
+        # training fast path without host read-backs of the sample counts (LSEOccGridEstimator.sampling(deferred=True)); the
+        # values are those of the synchronising path bit for bit.  Off by default: buffers are sized by a proven capacity
+        # (about 3x the samples in the reference's default configuration) instead of the exact count.
+        self.deferred_counts = False
         self.populate_modules()
         self.log_losses_dict = {"log_loss": self.log_loss, "enerf_norm_loss": self.enerf_norm_loss}
         self.rgb_losses_dic = {"linspace": self.mse_loss, "deblur": self.mse_loss}
@@ -424,6 +443,12 @@ class LSENeRFModel(nn.Module):
         assert self.field is not None
         num_rays = len(ray_bundle)
         cfg = self.config
+        if self.deferred_counts and self.training and self.sampler._packed_field is self.field and cfg.render_step_size > 0:
+            # no sample count visits the host: capacity-extent arrays + a device-side count handed to every per-sample kernel
+            ri, ts, te, packed, n_dev = self.sampler.sample_packed(
+                ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
+                alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter)
+            return self.render_packed(ray_bundle, ri, ts, te, packed, n_dev=n_dev)
         ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=cfg.near_plane,
                                                 far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
                                                 alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter)
@@ -432,12 +457,13 @@ class LSENeRFModel(nn.Module):
                                   ray_samples.frustums.ends[..., 0], ray_samples.packed_info)
 
     def render_packed(self, ray_bundle: RayBundle, ray_idx: Tensor, t_starts: Tensor, t_ends: Tensor,
-                      packed_info: Tensor) -> Dict[str, Tensor]:
-        """R:lse_nerf/lsenerf.py:297-326 on packed samples: field -> weights -> rgb / depth / accumulation."""
+                      packed_info: Tensor, n_dev: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """R:lse_nerf/lsenerf.py:297-326 on packed samples: field -> weights -> rgb / depth / accumulation.
+        ``n_dev``: device-side sample count when the packed arrays have capacity extent (deferred sampling)."""
         num_rays = len(ray_bundle)
         fld = self.field
         rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
-        sigma, h, _ = fld.density_packed(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
+        sigma, h, _ = fld.density_packed(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, n_dev)
         if fld.embedding_appearance is None:
             table, eidx = None, None
         elif fld.training:
@@ -446,7 +472,7 @@ class LSENeRFModel(nn.Module):
                                                         rays_o.device).contiguous()
         else:
             table, eidx = fld._eval_emb(num_rays, rays_o.device)
-        rgb16 = fld.rgb_packed(h, rays_d, eidx, ray_idx, packed_info, table)
+        rgb16 = fld.rgb_packed(h, rays_d, eidx, ray_idx, packed_info, table, n_dev)
         linear = isinstance(self.renderer_rgb, LinearRenderer)
         if not (self.training or linear):
             rgb16 = torch.nan_to_num(rgb16)

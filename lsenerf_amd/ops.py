@@ -46,6 +46,20 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _call_n(name: str, n_dev: Optional[torch.Tensor], *args):
+    """``_lib.call`` of a per-sample entry point with a device-side sample count (lse_set_device_count): the ``n`` among
+    ``args`` is then a CAPACITY and the kernels clamp it to ``n_dev[0]`` (int64, on the device).  ``n_dev is None``: plain call."""
+    if n_dev is None:
+        return _lib.call(name, *args)
+    assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() >= 1
+    lib = _lib.load()
+    lib.lse_set_device_count(ctypes.c_void_p(n_dev.data_ptr()))
+    try:
+        _lib.call(name, *args)
+    finally:
+        lib.lse_set_device_count(None)
+
+
 # ----------------------------------------------------------------------------------------------------
 # descriptors
 # ----------------------------------------------------------------------------------------------------
@@ -187,6 +201,70 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
 
 
 @torch.no_grad()
+def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
+                            cap: int):
+    """``traverse_grids`` without the host read-back of the sample count.  ``cap`` is a PROVEN upper bound of the samples of
+    one ray (LSEOccGridEstimator._cap_per_ray); the packed outputs have room for ``R * cap`` samples and the actual count stays
+    on the device.  Returns (ray_indices int32 [C], t_starts [C], t_ends [C], packed_info int64 [R,2], n_dev int64 [1],
+    overflow int32 [1]) with C = R * cap; entries at and beyond n_dev[0] are never written nor read by the kernels that are
+    handed ``n_dev``.  ``overflow`` != 0 would mean the bound was violated (checked lazily by the caller, never expected)."""
+    R = rays_o.shape[0]
+    L, rx, ry, rz = binaries.shape
+    dev = rays_o.device
+    C = R * cap
+    if not (0 < cap and C <= MAX_SLOT_ELEMS):
+        raise _lib.LseHipError(f"deferred sampling: {R} rays x {cap} slots exceed the slot budget ({MAX_SLOT_ELEMS})")
+    cnts = torch.empty(R, dtype=torch.int64, device=dev)
+    packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)
+    ts_slots = torch.empty(C, dtype=torch.float32, device=dev)
+    te_slots = torch.empty(C, dtype=torch.float32, device=dev)
+    flag = total[1:].view(torch.int32)
+    _lib.call("lse_traverse_grids_slots", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), R, _chk(binaries, torch.uint8, "binaries"),
+              _f32(aabbs, "aabbs"), L, rx, ry, rz, _f32(near_planes, "near_planes"), _f32(far_planes, "far_planes"),
+              float(step_size), float(cone_angle), cap, ctypes.c_void_p(cnts.data_ptr()), ctypes.c_void_p(ts_slots.data_ptr()),
+              ctypes.c_void_p(te_slots.data_ptr()), ctypes.c_void_p(flag.data_ptr()), _stream())
+    _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
+              ctypes.c_void_p(total.data_ptr()), _stream())
+    ri = torch.empty(C, dtype=torch.int32, device=dev)
+    ts = torch.empty(C, dtype=torch.float32, device=dev)
+    te = torch.empty(C, dtype=torch.float32, device=dev)
+    _lib.call("lse_compact_ray_slots", ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()), cap,
+              ctypes.c_void_p(packed.data_ptr()), R, ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()),
+              ctypes.c_void_p(te.data_ptr()), _stream())
+    return ri, ts, te, packed, total[0:1], flag[0:1]
+
+
+@torch.no_grad()
+def visibility_compact_deferred(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float,
+                                from_alpha: bool = False):
+    """``visibility_compact`` with the survivors' count left on the device: outputs keep the inputs' capacity.
+    Returns (ray_indices, t_starts, t_ends, packed_info, mask, n_dev)."""
+    R = packed_info.shape[0]
+    C = t_starts.shape[0]
+    dev = t_starts.device
+    mask = torch.empty(C, dtype=torch.uint8, device=dev)
+    new_cnts = torch.empty(R, dtype=torch.int64, device=dev)
+    if from_alpha:
+        _lib.call("lse_visibility_mask_alpha", _f32(sigmas, "alphas"), _chk(packed_info, torch.int64, "packed_info"), R,
+                  float(early_stop_eps), float(alpha_thre), ctypes.c_void_p(mask.data_ptr()),
+                  ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    else:
+        _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
+                  ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    new_packed, total = pack_info_from_counts(new_cnts)
+    o_ri = torch.empty(C, dtype=torch.int32, device=dev)
+    o_ts = torch.empty(C, dtype=torch.float32, device=dev)
+    o_te = torch.empty(C, dtype=torch.float32, device=dev)
+    _lib.call("lse_compact_samples", ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(packed_info.data_ptr()),
+              ctypes.c_void_p(new_packed.data_ptr()), R, _chk(ray_indices, torch.int32, "ray_indices"),
+              _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), ctypes.c_void_p(o_ri.data_ptr()),
+              ctypes.c_void_p(o_ts.data_ptr()), ctypes.c_void_p(o_te.data_ptr()), _stream())
+    return o_ri, o_ts, o_te, new_packed, mask, total[0:1]
+
+
+@torch.no_grad()
 def ray_planes(n_rays: int, device, near_plane: float, far_plane: float, t_min=None, t_max=None, jitter=None,
                step_size: float = 0.0):
     """(near_planes[R], far_planes[R]) of R:lse_nerf/lse_grid_estimator.py:83-92 in one launch."""
@@ -252,7 +330,7 @@ def visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early
 # ----------------------------------------------------------------------------------------------------
 class _PositionsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction: bool, aabb6, pre=None):
+    def forward(ctx, rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction: bool, aabb6, pre=None, n_dev=None):
         direct = ray_idx is None
         n = rays_o.shape[0] if direct else ray_idx.shape[0]
         if pre is not None:     # (x01, selector) already computed for exactly these samples by the visibility pre-pass
@@ -264,12 +342,12 @@ class _PositionsFn(torch.autograd.Function):
             x01 = torch.empty((n, 3), dtype=torch.float32, device=rays_o.device)
             sel = torch.empty(n, dtype=torch.uint8, device=rays_o.device)
             aabb_arr = (ctypes.c_float * 6)(*aabb6) if aabb6 is not None else None
-            _lib.call("lse_positions_fwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
+            _call_n("lse_positions_fwd", n_dev, _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
                       _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
                       _f32(t_ends, "t_ends", True), n, int(contraction), aabb_arr, ctypes.c_void_p(x01.data_ptr()),
                       ctypes.c_void_p(sel.data_ptr()), _stream())
         ctx.save_for_backward(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info)
-        ctx.contraction, ctx.aabb6, ctx.n = contraction, aabb6, n
+        ctx.contraction, ctx.aabb6, ctx.n, ctx.n_dev = contraction, aabb6, n, n_dev
         ctx.mark_non_differentiable(sel)
         return x01, sel
 
@@ -280,12 +358,12 @@ class _PositionsFn(torch.autograd.Function):
         d_x01 = _c(d_x01)
         d_pos = torch.empty((n, 3), dtype=torch.float32, device=d_x01.device)
         aabb_arr = (ctypes.c_float * 6)(*ctx.aabb6) if ctx.aabb6 is not None else None
-        _lib.call("lse_positions_bwd", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
+        _call_n("lse_positions_bwd", ctx.n_dev, _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d", True),
                   _chk(ray_idx, torch.int32, "ray_idx", True), _f32(t_starts, "t_starts", True),
                   _f32(t_ends, "t_ends", True), n, int(ctx.contraction), aabb_arr, _f32(d_x01, "d_x01"),
                   ctypes.c_void_p(d_pos.data_ptr()), _stream())
         if ray_idx is None:
-            return d_pos, None, None, None, None, None, None, None, None
+            return d_pos, None, None, None, None, None, None, None, None, None
         if packed_info is None:
             raise _lib.LseHipError("positions backward w.r.t. rays needs packed_info")
         R = rays_o.shape[0]
@@ -295,14 +373,15 @@ class _PositionsFn(torch.autograd.Function):
             _lib.call("lse_ray_grad_reduce", ctypes.c_void_p(d_pos.data_ptr()), _f32(t_starts, "t_starts"),
                       _f32(t_ends, "t_ends"), _chk(packed_info, torch.int64, "packed_info"), R,
                       _f32(d_o, "d_o", True), _f32(d_d, "d_d", True), _stream())
-        return d_o, d_d, None, None, None, None, None, None, None
+        return d_o, d_d, None, None, None, None, None, None, None, None
 
 
-def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction=True, aabb6=None, precomputed=None):
+def positions(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction=True, aabb6=None, precomputed=None,
+              n_dev=None):
     """Sample positions in the field's unit cube + in-bounds selector (R:lse_nerf/lse_field.py:266-274).
     ``ray_idx is None``: ``rays_o`` holds positions directly (Field.density_fn).  ``precomputed = (x01, selector)``: values
     the visibility pre-pass already produced for exactly these samples (only the autograd node is created)."""
-    return _PositionsFn.apply(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction, aabb6, precomputed)
+    return _PositionsFn.apply(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, contraction, aabb6, precomputed, n_dev)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -337,7 +416,7 @@ def hash_bwd_opts_with_workspace(desc: GridDesc, device) -> "_lib.HashBwdOpts":
 
 class _HashFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x01, table, meta: GridMeta, pre_y=None):
+    def forward(ctx, x01, table, meta: GridMeta, pre_y=None, n_dev=None):
         n = x01.shape[0]
         if pre_y is not None:      # features of exactly these positions, encoded by the visibility pre-pass with this table
             assert pre_y.shape == (meta.n_levels, n, meta.n_features)
@@ -345,10 +424,10 @@ class _HashFn(torch.autograd.Function):
         else:
             y = torch.empty((meta.n_levels, n, meta.n_features), dtype=torch.float32, device=x01.device)
             desc = meta.desc()
-            _lib.call("lse_hash_fwd", ctypes.byref(desc), _f32(x01, "x01"), _f32(table, "table"),
-                      ctypes.c_void_p(y.data_ptr()), n, _stream())
+            _call_n("lse_hash_fwd", n_dev, ctypes.byref(desc), _f32(x01, "x01"), _f32(table, "table"),
+                    ctypes.c_void_p(y.data_ptr()), n, _stream())
         ctx.save_for_backward(x01, table)
-        ctx.meta = meta
+        ctx.meta, ctx.n_dev = meta, n_dev
         return y
 
     @staticmethod
@@ -367,22 +446,23 @@ class _HashFn(torch.autograd.Function):
             # fine levels first (most of the table bytes); their gradients are final when the callback runs, so the caller
             # can start exchanging them while the coarse levels are still being computed (dist.OverlappedGradExchange)
             for lo, hi, acc in ((split[0], meta.n_levels, 0), (0, split[0], 1)):
-                _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
-                          ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), acc, lo, hi, n, ctypes.byref(opts), _stream())
+                _call_n("lse_hash_bwd_ex", ctx.n_dev, ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                        ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), acc, lo, hi, n, ctypes.byref(opts), _stream())
                 if acc == 0:
                     split[1]()
         else:
-            _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
-                      ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), 0, 0, meta.n_levels, n, ctypes.byref(opts),
-                      _stream())
-        return dx, (None if direct is not None else dtable), None, None
+            _call_n("lse_hash_bwd_ex", ctx.n_dev, ctypes.byref(desc), _f32(x01, "x01"), _f32(dy, "dy"), _f32(table, "table"),
+                    ctypes.c_void_p(dtable.data_ptr()), _f32(dx, "dx", True), 0, 0, meta.n_levels, n, ctypes.byref(opts),
+                    _stream())
+        return dx, (None if direct is not None else dtable), None, None, None
 
 
-def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta, precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
+def hash_encode(x01: torch.Tensor, table: torch.Tensor, meta: GridMeta, precomputed: Optional[torch.Tensor] = None,
+                n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tcnn HashGrid forward.  Returns level-major features y[L, N, F] (the fused MLP consumes this directly);
     ``y.permute(1, 0, 2).reshape(N, L*F)`` is the [N, L*F] tensor tcnn's torch binding returns.
     ``precomputed``: y already encoded for exactly these positions with this table (only the autograd node is created)."""
-    return _HashFn.apply(x01, table, meta, precomputed)
+    return _HashFn.apply(x01, table, meta, precomputed, n_dev)
 
 
 @torch.no_grad()
@@ -407,7 +487,7 @@ def compact_features(mask, packed_info, new_packed_info, n_new: int, x01, sel, y
 class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, x, row_bias, row_bias_idx, bias_packed_info, selector, meta: MlpMeta, n: int, out_cols: int,
-                density_scale):
+                density_scale, n_dev=None):
         dev = params.device
         out = torch.empty((n, out_cols), dtype=torch.float32, device=dev)
         sigma = torch.empty(n, dtype=torch.float32, device=dev) if density_scale is not None else None
@@ -431,12 +511,14 @@ class _MlpFn(torch.autograd.Function):
         act = torch.empty((n_saved, n_act, meta.width), dtype=torch.float32, device=dev) if (need_grad and tiled != 3) else None
         ctx.act_tiled = tiled
         desc = meta.desc()
-        _lib.call("lse_mlp_fwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
+        if n_dev is not None and need_grad and tiled != 3:
+            raise _lib.LseHipError("a device-side sample count needs the recomputing MLP kernels (width 64, head / base shape)")
+        _call_n("lse_mlp_fwd", n_dev, ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
                   _f32(row_bias, "row_bias", True), _chk(row_bias_idx, torch.int32, "row_bias_idx", True),
                   ctypes.c_void_p(out.data_ptr()), out_cols, _f32(act, "act", True), tiled, _f32(sigma, "sigma", True),
                   _chk(selector, torch.uint8, "selector", True), float(density_scale or 0.0), n, _stream())
         ctx.save_for_backward(params, x, act, out, row_bias, row_bias_idx, bias_packed_info, selector)
-        ctx.meta, ctx.n, ctx.out_cols, ctx.density_scale = meta, n, out_cols, density_scale
+        ctx.meta, ctx.n, ctx.out_cols, ctx.density_scale, ctx.n_dev = meta, n, out_cols, density_scale, n_dev
         ctx.set_materialize_grads(False)
         return out if sigma is None else (out, sigma)
 
@@ -459,7 +541,7 @@ class _MlpFn(torch.autograd.Function):
         scale = float(ctx.density_scale or 0.0)
         sel = _chk(selector, torch.uint8, "selector", True)
         if ctx.act_tiled or FUSED_WGRAD or d_params is None:
-            _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
+            _call_n("lse_mlp_bwd", ctx.n_dev, ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"),
                       _f32(act, "act", ctx.act_tiled == 3),
                       ctx.act_tiled, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       None, None, _f32(d_act0, "d_act0", True), _f32(d_in, "d_in", True),
@@ -489,7 +571,7 @@ class _MlpFn(torch.autograd.Function):
                           ctypes.c_void_p(d_bias.data_ptr()), _stream())
             else:   # unsorted row indices: generic scatter-add (not on the hot path)
                 d_bias = torch.zeros_like(row_bias).index_add_(0, row_bias_idx.long(), d_act0)
-        return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None
+        return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None, None
 
 
 HASH_BWD_SPLIT = None        # (level, callback) installed by dist.OverlappedGradExchange: two launches, callback in between
@@ -503,13 +585,13 @@ ACT_TILED = True      # tile-major saved activations (1 KiB contiguous per store
 
 
 def fused_mlp(params, x, meta: MlpMeta, n: int, row_bias=None, row_bias_idx=None, bias_packed_info=None,
-              out_cols: int = 16, density=None):
+              out_cols: int = 16, density=None, n_dev=None):
     """Bias-free fused MLP (tcnn layout).  Returns the padded output [n, 16] (or the compact [n, 4] = outputs 0..3).
     ``row_bias[rows, width]`` is added to the layer-0 pre-activation of sample i from row ``row_bias_idx[i]``;
     ``bias_packed_info[rows, 2]`` (start, count) must describe those rows' contiguous sample segments.
     ``density=(selector_or_None, scale)`` fuses the trunc_exp density head on output 0 and returns ``(out, sigma[n])``."""
     selector, scale = (None, None) if density is None else density
-    return _MlpFn.apply(params, x, row_bias, row_bias_idx, bias_packed_info, selector, meta, n, out_cols, scale)
+    return _MlpFn.apply(params, x, row_bias, row_bias_idx, bias_packed_info, selector, meta, n, out_cols, scale, n_dev)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -1,0 +1,131 @@
+"""Training fast path without host read-backs of the sample counts (LSENeRFModel.deferred_counts -> LSEOccGridEstimator.sampling
+(deferred=True) -> lse_set_device_count): the packed arrays have capacity extent, the counts stay on the device, every
+per-sample kernel clamps to them.  Values must be those of the synchronising path: renders and sample counts bit for bit (same
+kernels on the same samples), gradients up to the order of float-atomic summation."""
+import pytest
+import torch
+
+from tests.util import TOL_GRAD, nmax_err, random_binaries, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(**cfg_kw):
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig
+    torch.manual_seed(96)
+    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, **cfg_kw)
+    m = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 16)
+    with torch.no_grad():
+        m.field.mlp_base_grid.params.mul_(300.0)
+    m = m.cuda().train()
+    m.occupancy_grid.binaries.copy_(random_binaries(2, 32, 0.5, 3).cuda())
+    m.occupancy_grid.occs.copy_(m.occupancy_grid.binaries.flatten().float() * 0.5)
+    return m
+
+
+def _step(m, rb, jit, target):
+    for p in m.parameters():
+        p.grad = None
+    rb.origins.grad = rb.directions.grad = None
+    out = m.exec_get_outputs(rb, jitter=jit)
+    loss = torch.nn.functional.mse_loss(out["rgb"], target) + 0.1 * out["depth"].mean() + 0.05 * out["accumulation"].mean()
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    grads["origins"], grads["directions"] = rb.origins.grad.clone(), rb.directions.grad.clone()
+    return {k: v.detach().clone() for k, v in out.items()}, grads, float(loss.detach())
+
+
+@pytest.mark.parametrize("case", ["default_prepass_cone", "no_culling_constant_step"])
+def test_deferred_counts_equal_the_synchronising_path(case):
+    from lsenerf_amd import RayBundle, ops
+    kw = {} if case == "default_prepass_cone" else dict(cone_angle=0.0, alpha_thre=0.0)
+    m = _model(**kw)
+    R = 300
+    o, d = random_rays(R, seed=4)
+    g = torch.Generator().manual_seed(1)
+    rb = RayBundle(origins=o.cuda().requires_grad_(True), directions=d.cuda().requires_grad_(True),
+                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device="cuda"),
+                   metadata={"appearance_id": torch.randint(0, 16, (R,), generator=g).cuda()})
+    jit, target = torch.rand(R, generator=g).cuda(), torch.rand(R, 3, generator=g).cuda()
+    ops.SYNC_STATS.update(seconds=0.0, count=0)
+    out_s, g_s, l_s = _step(m, rb, jit, target)
+    n_sync = ops.SYNC_STATS["count"]
+    assert n_sync == 2          # marcher count + survivors of the cull (early_stop_eps > 0 keeps the pre-pass on in both cases)
+    m.deferred_counts = True
+    out_d, g_d, l_d = _step(m, rb, jit, target)
+    assert ops.SYNC_STATS["count"] == n_sync, "the deferred path read a sample count back to the host"
+    m.occupancy_grid.check_deferred_overflow()
+    assert int(out_s["num_samples_per_ray"].sum()) > 20 * R
+    for k in ("num_samples_per_ray", "rgb", "accumulation", "depth"):
+        assert torch.equal(out_s[k], out_d[k]), k
+    assert l_s == l_d
+    assert set(g_s) == set(g_d)
+    for k in g_s:
+        assert nmax_err(g_d[k], g_s[k], 1e-12) < 3e-5, k               # float atomics: two runs of one path differ as much
+    # a second deferred step on other rays (capacity buffers are recycled by the allocator: stale tails must not matter)
+    o2, d2 = random_rays(R, seed=5)
+    rb2 = RayBundle(origins=o2.cuda().requires_grad_(True), directions=d2.cuda().requires_grad_(True),
+                    camera_indices=rb.camera_indices, metadata=rb.metadata)
+    out_d2, g_d2, _ = _step(m, rb2, jit, target)
+    m.deferred_counts = False
+    out_s2, g_s2, _ = _step(m, rb2, jit, target)
+    for k in ("num_samples_per_ray", "rgb", "accumulation", "depth"):
+        assert torch.equal(out_s2[k], out_d2[k]), k
+    for k in g_s2:
+        assert nmax_err(g_d2[k], g_s2[k], 1e-12) < 3e-5, k
+
+
+def test_deferred_counts_with_no_sample_at_all_and_capacity_bound():
+    """Every ray misses every occupied cell: the device-side count is 0, every per-sample kernel leaves at once, the renders are
+    zero and the gradients vanish -- nothing reads the (uninitialised) capacity buffers.  And the capacity is what
+    _cap_per_ray promises: never smaller than the count of the synchronising path, for cone and constant steps."""
+    from lsenerf_amd import RayBundle
+    m = _model()
+    m.deferred_counts = True
+    m.occupancy_grid.binaries.zero_()
+    R = 64
+    o, d = random_rays(R, seed=2)
+    rb = RayBundle(origins=o.cuda().requires_grad_(True), directions=d.cuda().requires_grad_(True),
+                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device="cuda"),
+                   metadata={"appearance_id": torch.zeros(R, dtype=torch.long, device="cuda")})
+    out = m.exec_get_outputs(rb)
+    assert int(out["num_samples_per_ray"].sum()) == 0 and float(out["rgb"].abs().max()) == 0.0
+    out["rgb"].sum().backward()
+    assert float(m.field.mlp_base_grid.params.grad.abs().max()) == 0.0
+    # capacity bound against fully occupied grids (the worst case for the count)
+    m.occupancy_grid.binaries.fill_(True)
+    est = m.occupancy_grid
+    for cone in (0.0, 0.004, 0.02):
+        cap = est._cap_per_ray(0.05, 1e3, m.config.render_step_size, cone)
+        _, ts, _, packed = est.sampling(rb.origins.detach(), rb.directions.detach(), near_plane=0.05, far_plane=1e3,
+                                        render_step_size=m.config.render_step_size, cone_angle=cone, return_packed=True)
+        assert int(packed[:, 1].max()) <= cap and int(packed[:, 1].max()) > 100, (cone, cap, int(packed[:, 1].max()))
+    est.check_deferred_overflow()
+
+
+def test_train_step_bundles_deferred_equals_synced():
+    from lsenerf_amd import RayBundle
+    m = _model(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow")
+    g = torch.Generator().manual_seed(3)
+    sizes = (200, 50, 50)
+    bundles, jit = [], []
+    for i, n in enumerate(sizes):
+        o, d = random_rays(n, seed=40 + i)
+        bundles.append(RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"),
+                                 metadata={"appearance_id": torch.randint(0, 16, (n,), generator=g).cuda()}))
+        jit.append(torch.rand(n, generator=g).cuda())
+    batch = {"col_batch": {"image": torch.rand(sizes[0], 3, generator=g).cuda()},
+             "evs_batch": {"image": ((torch.rand(sizes[1], 1, generator=g) - 0.5) * 0.4).cuda()}}
+    res = []
+    for deferred in (False, True):
+        m.deferred_counts = deferred
+        for p in m.parameters():
+            p.grad = None
+        out, losses, _ = m.train_step_bundles(*bundles, batch, jitter=torch.cat(jit))
+        sum(losses.values()).backward()
+        res.append((out, {k: float(v) for k, v in losses.items()}, m.field.mlp_base_grid.params.grad.clone()))
+    (o0, l0, g0), (o1, l1, g1) = res
+    assert l0 == l1
+    for k in ("col_out", "prev_out", "next_out"):
+        assert torch.equal(o0[k]["rgb"], o1[k]["rgb"]) and torch.equal(o0[k]["num_samples_per_ray"], o1[k]["num_samples_per_ray"])
+    assert nmax_err(g1, g0, 1e-12) < 3e-5
