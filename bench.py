@@ -145,6 +145,35 @@ def _timed_steps(step_fn, steps, warmup, breakdown_steps=8):
     return ms, kern, launches
 
 
+def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None):
+    """The same step as ONE replayed HIP graph (lsenerf_amd.graph.GraphedTrainStep: device-side sample counts, staged Adam
+    scalars, jitter drawn inside the graph; the occupancy refresh stays an eager in-place call between replays).
+    Returns {"ms_per_step", "host_ms_per_step"}."""
+    from lsenerf_amd.graph import GraphedTrainStep
+    step = GraphedTrainStep(model, opt, col, prev, nxt, batch, ray_grads=True)
+    k = 0
+
+    def run(n):
+        nonlocal k
+        for _ in range(n):
+            if refresh_from is not None:
+                model.update_occupancy_grid(refresh_from + k)
+            step(col, prev, nxt, batch)
+            k += 1
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    step.check_overflow()
+    step.close()
+    return {"ms_per_step": ms, "host_ms_per_step": host / steps * 1e3,
+            "note": "one hipGraph replay per step (sampler with device-side counts -> field -> volume rendering -> loss epilogue -> "
+                    "backward -> Adam); occupancy refresh eager between replays"}
+
+
 def sphere_rays(R, gen):
     """SURVEY.md 8d ray distribution: origins uniform on the sphere of radius 1.5, aimed at uniform targets in [-0.5, 0.5]^3."""
     o = torch.randn(R, 3, generator=gen)
@@ -192,6 +221,9 @@ def context_default_config(device, steps=20, warmup=6):
 
     ms, kern, launches = _timed_steps(step, steps, warmup)
     kept = int(step.last["num_samples_per_ray"].sum())
+    graphed = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None}, steps, warmup,
+                              refresh_from=200)
+    graphed["rays_per_s"] = R / (graphed["ms_per_step"] * 1e-3)
     # candidates before culling: one more marcher call (untimed)
     with torch.no_grad():
         cand = est.sampling(rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=0.05, far_plane=1e3,
@@ -205,7 +237,7 @@ def context_default_config(device, steps=20, warmup=6):
             # ~2x the distinct table lines per sample of M-march), for comparison with the headline's
             # roofline.kernel_ms / samples_per_step
             "hash_bwd_ns_per_sample": kern.get("lse_hash_bwd", 0.0) * 1e6 / max(kept, 1),
-            "kernel_ms_per_step": kern, "launches_per_step": launches}
+            "graphed": graphed, "kernel_ms_per_step": kern, "launches_per_step": launches}
 
 
 def context_inside_box(device, steps=12, warmup=4):
@@ -305,6 +337,8 @@ def context_composition(device, kind, steps=16, warmup=6):
     kern, launches = _event_pass(step, warmup + steps, 8, None)
     kept = sum(int(v["num_samples_per_ray"].sum()) for v in last["out"].values() if v is not None)
     rays = sum(sizes)
+    graphed = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=200)
+    graphed["rays_per_s"] = rays / (graphed["ms_per_step"] * 1e-3)
     return {"workload": {"cfg2": "colour + prev + next event bundle (2316 / 597 / 597 rays), co_map routing, rgb + event loss",
                          "cfg4": "BAD-NeRF deblur: 878 pixels x 4 virtual cameras = 3512 rays, rgb loss on the 4-ray mean, pose gradients"}[kind]
                         + "; ONE packed pass per step (train_step_bundles), reference default sampler configuration, carved grid, "
@@ -314,7 +348,7 @@ def context_composition(device, kind, steps=16, warmup=6):
             "host_blocked_in_count_readbacks_ms_per_step": blocked / steps * 1e3, "count_readbacks_per_step": n_sync / steps,
             "host_python_ms_per_step": (host_issue - blocked) / steps * 1e3,
             "launches_per_step": sum(launches.values()), "kernel_ms_sum_per_step": sum(kern.values()),
-            "kernel_ms_per_step": kern}
+            "graphed": graphed, "kernel_ms_per_step": kern}
 
 
 def context_m_packed(device, steps=12, warmup=4):
@@ -523,6 +557,11 @@ def main():
             "loss": float(loss.detach()),
         }
         if world == 1 and not args.no_context:
+            # the headline workload as one replayed graph (pre-pass off as SURVEY 8d prescribes: no density_fn on the sampler)
+            model.sampler.density_fn = None
+            line["m_march_graphed"] = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
+                                                      min(args.steps, 20), 4)
+            line["m_march_graphed"]["rays_per_s"] = RAYS_PER_GPU / (line["m_march_graphed"]["ms_per_step"] * 1e-3)
             del model, flat, opt
             torch.cuda.empty_cache()
             line["m_march_inside_box"] = context_inside_box(device)

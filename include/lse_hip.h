@@ -115,6 +115,11 @@ int lse_ray_planes(float near_plane, float far_plane, const float *t_min, const 
 int lse_visibility_mask(const float *t_starts, const float *t_ends, const float *sigmas,
                         const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
                         uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
+/* The same with R:lse_nerf/lse_grid_estimator.py:112-116's `alpha_thre = min(alpha_thre, self.occs.mean().item())` evaluated on
+ * the device: alpha_cap points to occs.mean() in device memory (no host read-back; a captured launch follows grid refreshes). */
+int lse_visibility_mask_cap(const float *t_starts, const float *t_ends, const float *sigmas,
+                            const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
+                            const float *alpha_cap, uint8_t *mask, int64_t *new_cnts, lse_stream_t stream);
 /* Survivors of the visibility culling keep what the sigma_fn pre-pass computed for them: x01[N,3], selector[N] and the
  * level-major hash features y[L][N][2] (F = 2) are compacted with the same mask / packed_info pair as
  * lse_compact_samples, so the main field pass does not encode them again (R:lse_nerf/lse_grid_estimator.py:109-143 evaluates
@@ -376,6 +381,10 @@ int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, c
 /* ---- optimiser: torch.optim.Adam semantics on a flat buffer (R:lse_nerf/lse_config.py:29-33) ----------- */
 int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream);
+/* The same with the step-dependent scalars in device memory: hyper[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)}.  A launch
+ * captured into a HIP graph cannot carry new scalar arguments; the host refreshes these three floats before every replay. */
+int lse_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *hyper,
+                      float beta1, float beta2, float eps, float grad_scale, lse_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lse_ray_planes": [F32, F32, P, P, P, F32, I32, P, P, P],
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
     "lse_visibility_mask_alpha": [P, P, I32, F32, F32, P, P, P],
+    "lse_visibility_mask_cap": [P, P, P, P, I32, F32, F32, P, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
     "lse_compact_features": [P, P, P, I32, P, P, P, I32, I64, I64, P, P, P, P],
     "lse_positions_fwd": [P, P, P, P, P, I64, I32, P, P, P, P],
@@ -91,6 +92,7 @@ SIGNATURES = {
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],
+    "lse_adam_step_dev": [P, P, P, P, I64, P, F32, F32, F32, F32, P],
 }
 
 _lib = None

@@ -10,8 +10,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float bc1, float inv_sqrt_bc2,
-                                                   float gscale)
+                                                   float gscale, const float *__restrict__ hyper)
 {
+    if (hyper != nullptr) {      // step-dependent scalars from device memory (a captured launch cannot carry new ones)
+        lr = hyper[0];
+        bc1 = hyper[1];
+        inv_sqrt_bc2 = hyper[2];
+    }
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float step = lr / bc1;
@@ -89,8 +94,23 @@ extern "C" int lse_adam_step(float *params, const float *grads, float *exp_avg, 
     const int64_t n4 = (n + 3) / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 2048));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
-                       n, lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+                       n, lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, (const float *)nullptr);
     return lse::check_launch("lse_adam_step");
+}
+
+extern "C" int lse_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                 const float *hyper, float beta1, float beta2, float eps, float grad_scale, lse_stream_t stream)
+{
+    LSE_REQUIRE(n >= 0, "lse_adam_step_dev: n < 0");
+    if (n == 0) return LSE_OK;
+    LSE_REQUIRE(params && grads && exp_avg && exp_avg_sq && hyper, "lse_adam_step_dev: null pointer");
+    LSE_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "lse_adam_step_dev: buffers must be 16-byte aligned");
+    const int64_t n4 = (n + 3) / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 2048));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
+                       n, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, hyper);
+    return lse::check_launch("lse_adam_step_dev");
 }
 
 extern "C" int lse_occ_update_cells(float *occs, const int64_t *cell_ids, const float *occ_new, int64_t n,

@@ -177,10 +177,12 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
                                                          const float *__restrict__ sigma,
                                                          const int64_t *__restrict__ packed, int n_rays, float eps,
                                                          float alpha_thre, uint8_t *__restrict__ mask,
-                                                         int64_t *__restrict__ new_cnts, int from_alpha)
+                                                         int64_t *__restrict__ new_cnts, int from_alpha,
+                                                         const float *__restrict__ alpha_cap)
 {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
+    if (alpha_cap != nullptr) alpha_thre = fminf(alpha_thre, *alpha_cap);      // min(alpha_thre, occs.mean()) without the .item()
     const int lane = threadIdx.x & 63;
     const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
     float carry = 0.f;
@@ -378,8 +380,20 @@ extern "C" int lse_visibility_mask(const float *t_starts, const float *t_ends, c
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && mask, "lse_visibility_mask: null pointer");
     hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
-                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts, 0);
+                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts, 0, (const float *)nullptr);
     return lse::check_launch("lse_visibility_mask");
+}
+
+extern "C" int lse_visibility_mask_cap(const float *t_starts, const float *t_ends, const float *sigmas,
+                                       const int64_t *packed_info, int32_t n_rays, float early_stop_eps, float alpha_thre,
+                                       const float *alpha_cap, uint8_t *mask, int64_t *new_cnts, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_visibility_mask_cap: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(t_starts && t_ends && sigmas && packed_info && mask && alpha_cap, "lse_visibility_mask_cap: null pointer");
+    hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), t_starts, t_ends,
+                       sigmas, packed_info, n_rays, early_stop_eps, alpha_thre, mask, new_cnts, 0, alpha_cap);
+    return lse::check_launch("lse_visibility_mask_cap");
 }
 
 extern "C" int lse_visibility_mask_alpha(const float *alphas, const int64_t *packed_info, int32_t n_rays,
@@ -391,7 +405,7 @@ extern "C" int lse_visibility_mask_alpha(const float *alphas, const int64_t *pac
     LSE_REQUIRE(alphas && packed_info && mask, "lse_visibility_mask_alpha: null pointer");
     hipLaunchKernelGGL(visibility_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream),
                        (const float *)nullptr, (const float *)nullptr, alphas, packed_info, n_rays, early_stop_eps,
-                       alpha_thre, mask, new_cnts, 1);
+                       alpha_thre, mask, new_cnts, 1, (const float *)nullptr);
     return lse::check_launch("lse_visibility_mask_alpha");
 }
 

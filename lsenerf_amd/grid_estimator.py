@@ -90,6 +90,19 @@ class LSEOccGridEstimator(nn.Module):
                 n += math.log(t1 / max(tc, t0, 1e-30)) / math.log1p(cone)
         return int(n) + 16 + 4 * self.levels
 
+    @torch.no_grad()
+    def _occ_mean_device(self) -> Tensor:
+        """occs.mean() as a float32 [1] device tensor at a fixed address, recomputed (on the device) when `occs` has been
+        written since the last call."""
+        buf = self.__dict__.get("_occ_mean_dev")
+        if buf is None or buf.device != self.occs.device:
+            buf = self.__dict__["_occ_mean_dev"] = torch.zeros(1, dtype=torch.float32, device=self.occs.device)
+            self.__dict__["_occ_mean_dev_version"] = None
+        if self.__dict__.get("_occ_mean_dev_version") != self.occs._version:
+            buf.copy_(self.occs.mean().reshape(1))
+            self.__dict__["_occ_mean_dev_version"] = self.occs._version
+        return buf
+
     def check_deferred_overflow(self) -> None:
         """Deferred sampling never reads the marcher's slot-overflow flag on the critical path (the capacity is a proven
         bound); this reads the flags of the calls made so far -- one host synchronisation -- and raises if one is set."""
@@ -173,9 +186,9 @@ class LSEOccGridEstimator(nn.Module):
         if self.after_march_hook is not None:
             self.after_march_hook()
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
-            if self._occ_mean_host is None:
-                self._occ_mean_host = self.occs.mean().item()     # (after a grid refresh only: not on the per-step path)
-            alpha_thre = min(alpha_thre, self._occ_mean_host)
+            # `alpha_thre = min(alpha_thre, self.occs.mean().item())` of the reference, with the mean kept on the device
+            # (refreshed in place whenever `occs` has been written): no read-back, and a captured launch follows grid refreshes
+            alpha_cap = self._occ_mean_device()
             with torch.no_grad():
                 if sigma_fn is not None:
                     try:
@@ -189,7 +202,7 @@ class LSEOccGridEstimator(nn.Module):
             old_packed = packed_info
             ray_indices, t_starts, t_ends, packed_info, mask, n_dev = ops.visibility_compact_deferred(
                 ray_indices, t_starts, t_ends, vals.contiguous(), packed_info, early_stop_eps, alpha_thre,
-                from_alpha=sigma_fn is None)
+                from_alpha=sigma_fn is None, alpha_cap=alpha_cap)
             on_cull = getattr(sigma_fn, "on_cull", None) if sigma_fn is not None else None
             if on_cull is not None:
                 on_cull(mask, old_packed, packed_info, ray_indices, t_starts, t_ends)

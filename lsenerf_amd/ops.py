@@ -237,8 +237,9 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
 
 @torch.no_grad()
 def visibility_compact_deferred(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float,
-                                from_alpha: bool = False):
+                                from_alpha: bool = False, alpha_cap: Optional[torch.Tensor] = None):
     """``visibility_compact`` with the survivors' count left on the device: outputs keep the inputs' capacity.
+    ``alpha_cap``: float32 [1] on the device; the threshold used is min(alpha_thre, alpha_cap[0]) (lse_visibility_mask_cap).
     Returns (ray_indices, t_starts, t_ends, packed_info, mask, n_dev)."""
     R = packed_info.shape[0]
     C = t_starts.shape[0]
@@ -249,6 +250,10 @@ def visibility_compact_deferred(ray_indices, t_starts, t_ends, sigmas, packed_in
         _lib.call("lse_visibility_mask_alpha", _f32(sigmas, "alphas"), _chk(packed_info, torch.int64, "packed_info"), R,
                   float(early_stop_eps), float(alpha_thre), ctypes.c_void_p(mask.data_ptr()),
                   ctypes.c_void_p(new_cnts.data_ptr()), _stream())
+    elif alpha_cap is not None:
+        _lib.call("lse_visibility_mask_cap", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
+                  _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
+                  _f32(alpha_cap, "alpha_cap"), ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(new_cnts.data_ptr()), _stream())
     else:
         _lib.call("lse_visibility_mask", _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends"), _f32(sigmas, "sigmas"),
                   _chk(packed_info, torch.int64, "packed_info"), R, float(early_stop_eps), float(alpha_thre),
@@ -926,6 +931,14 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step: i
     _lib.call("lse_adam_step", _f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"),
               _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), float(lr), float(beta1), float(beta2), float(eps),
               int(step), float(grad_scale), _stream())
+
+
+@torch.no_grad()
+def adam_step_dev(params, grads, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, grad_scale: float = 1.0):
+    """Adam with the step-dependent scalars (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) in ``hyper`` (float32 [3] on the device)."""
+    _lib.call("lse_adam_step_dev", _f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"),
+              _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), _f32(hyper, "hyper"), float(beta1), float(beta2), float(eps),
+              float(grad_scale), _stream())
 
 
 @torch.no_grad()

@@ -75,6 +75,26 @@ class FlatAdam:
         ops.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                       self.eps, self.step_count, grad_scale)
 
+    # -- captured steps: the launch inside a HIP graph cannot carry this step's scalars, so they live in device memory ----------
+    def prepare_step(self) -> None:
+        """Advance the step count and stage (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) of the NEW step in device memory (an
+        asynchronous 12-byte copy on the current stream).  Call before replaying a graph that contains ``step_staged``."""
+        import math
+        lr = self.current_lr()
+        self.step_count += 1
+        if not hasattr(self, "_hyper_host"):
+            self._hyper_host = torch.empty(3, dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.empty(3, dtype=torch.float32, device=self.flat.data.device)
+        self._hyper_host[0] = lr
+        self._hyper_host[1] = 1.0 - self.betas[0] ** self.step_count
+        self._hyper_host[2] = 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def step_staged(self, grad_scale: float = 1.0) -> None:
+        """The Adam update with the scalars ``prepare_step`` staged (lse_adam_step_dev): capturable."""
+        ops.adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self._hyper_dev, self.betas[0],
+                          self.betas[1], self.eps, grad_scale)
+
     # -- resume (nerfstudio saves ``optimizers: {"fields": optimizer.state_dict()}``, R:lse_nerf/lse_trainer.py:85-122) ------
     def state_dict(self) -> dict:
         """torch.optim.Adam-style state dict (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` + one param group), so

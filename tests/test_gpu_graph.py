@@ -1,0 +1,104 @@
+"""The whole training step as one replayed HIP graph (lsenerf_amd.graph.GraphedTrainStep): sampler with device-side counts,
+visibility pre-pass, field, volume rendering, fused loss epilogue, backward, Adam with staged scalars.  The replayed step must
+be the eager step: same losses and gradients on the same rays / targets / jitter, following in-place occupancy refreshes and
+the learning-rate schedule from step to step."""
+import copy
+
+import pytest
+import torch
+
+from tests.util import nmax_err, random_binaries, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ray_grads):
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    torch.manual_seed(96)
+    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, use_mapping=True, mapping_method="identity",
+                             map_mode="co_map", evs_mapping_method="powpow")
+    models, opts = [], []
+    base = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 16)
+    with torch.no_grad():
+        base.field.mlp_base_grid.params.mul_(300.0)
+    for _ in range(2):
+        m = copy.deepcopy(base).cuda().train()
+        m.occupancy_grid.binaries.copy_(random_binaries(2, 32, 0.5, 3).cuda())
+        m.occupancy_grid.occs.copy_(m.occupancy_grid.binaries.flatten().float() * 0.5)
+        flat = FlatParams(m.get_param_groups()["fields"])
+        models.append(m)
+        opts.append(FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=50))     # a schedule that moves visibly
+    g = torch.Generator().manual_seed(3)
+    sizes = (200, 50, 50)
+
+    def batch_of(seed):
+        bundles = []
+        for i, n in enumerate(sizes):
+            o, d = random_rays(n, seed=seed + i)
+            bundles.append(RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"),
+                                     metadata={"appearance_id": torch.randint(0, 16, (n,), generator=g).cuda()}))
+        batch = {"col_batch": {"image": torch.rand(sizes[0], 3, generator=g).cuda()},
+                 "evs_batch": {"image": ((torch.rand(sizes[1], 1, generator=g) - 0.5) * 0.4).cuda()}}
+        return bundles, batch, torch.rand(sum(sizes), generator=g).cuda()
+    return models, opts, batch_of
+
+
+def _eager_step(m, opt, bundles, batch, jit, ray_grads):
+    opt.zero_grad()
+    bs = bundles
+    if ray_grads:
+        from lsenerf_amd import RayBundle
+        bs = [RayBundle(origins=b.origins.clone().requires_grad_(True), directions=b.directions.clone().requires_grad_(True),
+                        camera_indices=b.camera_indices, metadata=b.metadata) for b in bundles]
+    _, losses, _ = m.train_step_bundles(*bs, batch, jitter=jit)
+    sum(losses.values()).backward()
+    grad = opt.flat.grad.clone()
+    opt.step()
+    return {k: float(v) for k, v in losses.items()}, grad, bs
+
+
+@pytest.mark.parametrize("ray_grads", [False, True])
+def test_graphed_step_equals_eager_step(ray_grads):
+    from lsenerf_amd import ops
+    from lsenerf_amd.graph import GraphedTrainStep
+    (m_e, m_g), (o_e, o_g), batch_of = _setup(ray_grads)
+    b0, batch0, jit0 = batch_of(50)
+    step = GraphedTrainStep(m_g, o_g, *b0, batch0, ray_grads=ray_grads, jitter="input")
+    assert o_g.step_count == 0 and torch.equal(o_g.flat.data, o_e.flat.data)        # building the graph trains nothing
+    ops.SYNC_STATS.update(seconds=0.0, count=0)
+    spans = [(o, o + p.numel()) for p, o in zip(o_e.flat.params, o_e.flat.offsets)]
+    for it in range(4):
+        if it == 2:                      # an occupancy refresh between replays: in place, outside the graph
+            for m in (m_e, m_g):
+                m.update_occupancy_grid(0)
+        bundles, batch, jit = batch_of(60 + 10 * it)
+        sync_before = ops.SYNC_STATS["count"]
+        l_g = {k: v for k, v in step(*bundles, batch, jitter=jit).items()}
+        assert ops.SYNC_STATS["count"] == sync_before                                    # no sample count visited the host
+        g_g = o_g.flat.grad.clone()
+        l_g = {k: float(v) for k, v in l_g.items()}
+        l_e, g_e, bs = _eager_step(m_e, o_e, bundles, batch, jit, ray_grads)
+        assert set(l_g) == set(l_e) == {"rgb_loss", "event_loss"}
+        for k in l_e:
+            assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (it, k, l_g[k], l_e[k])
+        if it == 0:      # identical parameters: the gradients agree to float-atomic noise, tensor by tensor
+            for a, b in spans:
+                assert nmax_err(g_g[a:b], g_e[a:b], 1e-12) < 3e-5, (a, b)
+            if ray_grads:
+                rg = step.ray_grads
+                for key, be in zip(("col", "prev", "next"), bs):
+                    assert nmax_err(rg[key][0], be.origins.grad, 1e-12) < 3e-5 and nmax_err(rg[key][1], be.directions.grad, 1e-12) < 3e-5
+        assert o_g.step_count == o_e.step_count == it + 1
+    step.check_overflow()
+    # after four Adam steps (eps 1e-15 turns summation noise into +-lr steps) the parameters still agree
+    # except for a small fraction of noise-dominated elements
+    d = (o_g.flat.data - o_e.flat.data).abs()
+    scale = float(o_e.flat.data.abs().max())
+    assert float((d > 1e-5 * scale).float().mean()) < 0.02
+    # composition changes are refused loudly
+    bundles, batch, jit = batch_of(99)
+    with pytest.raises(ValueError, match="fixed"):
+        step(bundles[0], None, None, batch, jitter=jit)
+    step.close()
+    assert m_g.deferred_counts is False
