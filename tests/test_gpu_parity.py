@@ -590,6 +590,56 @@ def test_bf16_piece_arithmetic_has_the_error_level_of_f32(head):
     assert errs[2] <= 2 * errs[1] + 1e-7, errs
 
 
+def test_bf16_piece_arithmetic_on_extreme_and_non_finite_inputs():
+    """The bf16-piece forward at the ends of the exponent range and on non-finite inputs (base shape: 32 inputs, ReLU, linear
+    output -- positively homogeneous, so f(s x) / s must equal f(x)).
+      * inputs scaled by 2^60 and by 2^-60: bf16 has f32's exponent range, the three pieces of a value span 2^-16 of its
+        magnitude, so neither end loses a piece: the relative error against float64 stays at the f32 level (< 1e-6), as unscaled;
+      * one input row holding +inf, one holding NaN: the remainder of a piece is formed on the matrix core as D = C - I * hi, so an
+        infinite input gives inf - inf = NaN where true f32 arithmetic would give +-inf -- those two rows come back non-finite (NaN),
+        and EVERY other row is bit-identical to the run without them (a matrix-core column never mixes samples)."""
+    import ctypes
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    N = 4096 + 37
+    meta = ops.MlpMeta(32, 64, 1, _lib.LSE_ACT_NONE, _lib.LSE_IN_LEVELMAJOR)
+    params = (torch.randn(32 * 64 + 16 * 64, generator=g) * 0.2).cuda()
+    x = torch.randn(N, 32, generator=g)
+    desc = meta.desc()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def run(xx):
+        xin = xx.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda()
+        out = torch.empty(N, 16, device="cuda")
+        _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(params), P(xin), None, None, P(out), 16, None, 1, None, None, 0.0, N, ops._stream())
+        return out.cpu()
+    pd = params.double().cpu()
+    ref = torch.relu(x.double() @ pd[:2048].view(64, 32).T) @ pd[2048:].view(16, 64).T
+    old = _lib.get_option("mlp_fwd_impl")
+    try:
+        _lib.set_option("mlp_fwd_impl", 2)
+        base = run(x)
+        assert float((base.double() - ref).abs().max() / ref.abs().max()) < 1e-6
+        for e in (60, -60):
+            sc = float(2.0 ** e)
+            out = run(x * sc)
+            assert torch.isfinite(out).all(), e
+            err = float((out.double() / sc - ref).abs().max() / ref.abs().max())
+            assert err < 1e-6, (e, err)
+        bad = x.clone()
+        bad[100, 3] = float("inf")
+        bad[2000, 17] = float("nan")
+        out = run(bad)
+        print("inf row ->", out[100].tolist(), "\nnan row ->", out[2000].tolist())
+        assert not torch.isfinite(out[100]).all() and not torch.isfinite(out[2000]).all()
+        keep = torch.ones(N, dtype=torch.bool)
+        keep[100] = keep[2000] = False
+        assert torch.equal(out[keep], base[keep])
+    finally:
+        _lib.set_option("mlp_fwd_impl", old)
+
+
 @pytest.mark.parametrize("pattern", ["short", "mixed", "tile_aligned", "long"])
 def test_mlp_head_view_bias_column_row_patterns(pattern):
     """The head as the field calls it (first-layer view: leading dimension 64, column offset 15, column 0 masked, compact 4-column
