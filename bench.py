@@ -85,32 +85,36 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
     rb.origins.grad = None
     rb.directions.grad = None
     cfg = model.config
-    ri, ts, te, packed = model.occupancy_grid.sampling(
+    # the sample count stays on the device (deferred=True: capacity-extent packed arrays + n_dev handed to every per-sample
+    # kernel); values are those of the synchronising path bit for bit (tests/test_gpu_deferred.py)
+    res = model.occupancy_grid.sampling(
         rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         t_max=rb.fars.reshape(-1) if rb.fars is not None else None, render_step_size=cfg.render_step_size, stratified=True, cone_angle=cfg.cone_angle,
-        alpha_thre=cfg.alpha_thre, jitter=jitter, return_packed=True)
+        alpha_thre=cfg.alpha_thre, jitter=jitter, **({"deferred": True} if model.use_deferred_counts(len(rb)) else {"return_packed": True}))
+    ri, ts, te, packed = res[:4]
+    n_dev = res[4] if len(res) == 5 else None       # (None: the model's slot budget sent this batch down the synchronising path)
     # (pipelined exchange: the all-reduce + Adam of the previous step finished inside sampling(), right after the marcher,
     #  through the estimator's after_march_hook -- dist.GradPipeline.attach)
     opt.zero_grad()
-    out = model.render_packed(rb, ri, ts, te, packed)
+    out = model.render_packed(rb, ri, ts, te, packed, n_dev=n_dev)
     # routing (training clamp) + rgb MSE in the fused epilogue kernel pair, as the training step does
     loss = model.fused_loss_dict({"col_out": out, "prev_out": None, "next_out": None},
                                  {"col_batch": {"image": target}, "evs_batch": None})["rgb_loss"]
     loss.backward()
     if pipeline is not None:
         pipeline.start()
-        return ri.shape[0], loss
+        return (n_dev if n_dev is not None else ri.shape[0]), loss
     if sharded is not None:        # reduce-scatter -> Adam on this rank's 1/W shard -> all-gather
         sharded.lr = opt.current_lr()
         opt.step_count += 1
         sharded.step()
-        return ri.shape[0], loss
+        return (n_dev if n_dev is not None else ri.shape[0]), loss
     if exchange is not None:
         exchange.finish()          # the fine levels' table gradients have been in flight since the middle of the hash backward
     elif world > 1:
         ldist.allreduce_grads(opt.flat.grad)
     opt.step(grad_scale=1.0 / world)
-    return ri.shape[0], loss
+    return (n_dev if n_dev is not None else ri.shape[0]), loss
 
 
 def _event_pass(step_fn, first, steps, names):
@@ -252,7 +256,7 @@ def context_inside_box(device, steps=12, warmup=4):
         last["n"], _ = train_step(model, rb, target, jitter, opt, 1)
 
     ms, kern, _ = _timed_steps(step, steps, warmup)
-    n = last["n"]
+    n = int(last["n"])
     return {"workload": "M-march as benchmarked in rounds 1-2: origins in [-0.5,0.5]^3, 4-level 128^3 grid fully occupied, per-ray "
                         "t_max capped -> exactly 1024 samples per ray (65 % of them in the contracted shell, where consecutive "
                         "samples share fine cells: the friendlier input)",
@@ -323,17 +327,23 @@ def context_composition(device, kind, steps=16, warmup=6):
         last["out"] = out
 
     from lsenerf_amd import ops as _ops
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    _ops.SYNC_STATS.update(seconds=0.0, count=0)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i)
-    host_issue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    blocked, n_sync = _ops.SYNC_STATS["seconds"], _ops.SYNC_STATS["count"]
+
+    def timed(deferred):
+        model.deferred_counts = deferred
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        _ops.SYNC_STATS.update(seconds=0.0, count=0)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, host, _ops.SYNC_STATS["seconds"], _ops.SYNC_STATS["count"]
+    # (a) the synchronising eager step (two read-backs of the sampler's counts), (b) the eager step with device-side counts
+    ms_sync, host_sync, blocked, n_sync = timed(False)
+    ms, host_issue, _, n_sync_deferred = timed(True)
+    assert n_sync_deferred == 0
     kern, launches = _event_pass(step, warmup + steps, 8, None)
     kept = sum(int(v["num_samples_per_ray"].sum()) for v in last["out"].values() if v is not None)
     rays = sum(sizes)
@@ -345,8 +355,11 @@ def context_composition(device, kind, steps=16, warmup=6):
                           "refresh every 16 steps inside the timing",
             "rays": rays, "steps": steps, "ms_per_step": ms, "rays_per_s": rays / (ms * 1e-3),
             "samples_per_ray_after_culling": kept / rays, "host_issue_ms_per_step": host_issue / steps * 1e3,
-            "host_blocked_in_count_readbacks_ms_per_step": blocked / steps * 1e3, "count_readbacks_per_step": n_sync / steps,
-            "host_python_ms_per_step": (host_issue - blocked) / steps * 1e3,
+            "eager_synchronising": {"ms_per_step": ms_sync, "host_issue_ms_per_step": host_sync / steps * 1e3,
+                                    "host_blocked_in_count_readbacks_ms_per_step": blocked / steps * 1e3,
+                                    "count_readbacks_per_step": n_sync / steps,
+                                    "host_python_ms_per_step": (host_sync - blocked) / steps * 1e3,
+                                    "note": "LSENeRFModel.deferred_counts = False: the sampler reads its two counts back"},
             "launches_per_step": sum(launches.values()), "kernel_ms_sum_per_step": sum(kern.values()),
             "graphed": graphed, "kernel_ms_per_step": kern}
 
@@ -494,6 +507,8 @@ def main():
     timing = _lib.TIMING
     _lib.TIMING = None
     elapsed = ldist.max_over_ranks(elapsed, device)
+    n_samples = int(n_samples)                 # the device-side count of the last step, read once, after the timed region
+    model.occupancy_grid.check_deferred_overflow()
 
     per_kernel = {}
     for name, e0, e1 in timing["events"]:
@@ -554,6 +569,8 @@ def main():
             "kernel_ms_note": "per C-ABI entry point, from a separate instrumented pass of %d steps (event pairs around every "
                               "entry point perturb the step; the timed region instruments the two hash kernels only)" % bsteps,
             "host_issue_ms_per_step": host_issue / args.steps * 1e3,
+            "host_issue_note": "host time to issue the K timed steps; no sample count is read back (device-side counts), so this is "
+                               "Python + launch time and the host runs ahead of the GPU",
             "loss": float(loss.detach()),
         }
         if world == 1 and not args.no_context:

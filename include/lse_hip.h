@@ -103,6 +103,10 @@ int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, 
 /* nerfacc.pack_info (R:lse_nerf/lsenerf.py:300): packed_info[R,2] = (exclusive cumsum, count); total[1]. */
 int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info, int64_t *total,
                               lse_stream_t stream);
+/* nerfstudio VolumetricSampler.forward: "if num_samples == 0: create a single fake sample" (ray 0, starts = ends = 1,
+ * packed_info[0] = (0, 1)) -- applied on the device to a device-side count (*n_dev == 0 -> 1).  Arrays need room for 1 sample. */
+int lse_fake_sample_if_empty(int64_t *packed_info, int32_t n_rays, int64_t *n_dev, int32_t *ray_indices, float *t_starts,
+                             float *t_ends, lse_stream_t stream);
 
 /* Per-ray near / far planes of R:lse_nerf/lse_grid_estimator.py:83-92 in one launch (bit-identical to the torch ops):
  * near = max(near_plane, t_min[r]) (+ jitter[r] * step_size when jitter is given: stratified sampling),

@@ -367,6 +367,21 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 }
 
 // single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
+// nerfstudio's VolumetricSampler inserts ONE fake sample (ray 0, t_start = t_end = 1) when no ray produced any, so that nothing
+// downstream sees empty tensors; with the count on the device the same rule is applied there
+__global__ void fake_sample_kernel(int64_t *__restrict__ packed, int64_t *__restrict__ n_dev, int32_t *__restrict__ ri,
+                                   float *__restrict__ ts, float *__restrict__ te)
+{
+    if (threadIdx.x == 0 && *n_dev == 0) {
+        packed[0] = 0;
+        packed[1] = 1;
+        ri[0] = 0;
+        ts[0] = 1.f;
+        te[0] = 1.f;
+        *n_dev = 1;
+    }
+}
+
 __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t *__restrict__ cnts, int n, int64_t *packed,
                                                          int64_t *total)
 {
@@ -513,6 +528,17 @@ extern "C" int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_ra
     hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(1024), 0, lse::as_stream(stream), chunk_cnts, n_rays, packed_info,
                        total);
     return lse::check_launch("lse_pack_info_from_counts");
+}
+
+extern "C" int lse_fake_sample_if_empty(int64_t *packed_info, int32_t n_rays, int64_t *n_dev, int32_t *ray_indices,
+                                        float *t_starts, float *t_ends, lse_stream_t stream)
+{
+    LSE_REQUIRE(n_rays >= 0, "lse_fake_sample_if_empty: n_rays < 0");
+    if (n_rays == 0) return LSE_OK;
+    LSE_REQUIRE(packed_info && n_dev && ray_indices && t_starts && t_ends, "lse_fake_sample_if_empty: null pointer");
+    hipLaunchKernelGGL(fake_sample_kernel, dim3(1), dim3(64), 0, lse::as_stream(stream), packed_info, n_dev, ray_indices, t_starts,
+                       t_ends);
+    return lse::check_launch("lse_fake_sample_if_empty");
 }
 
 extern "C" int lse_ray_planes(float near_plane, float far_plane, const float *t_min, const float *t_max,

@@ -112,8 +112,8 @@ class GraphedTrainStep:
         assert jitter in ("graph", "input")
         assert model.training, "the captured step is the training step"
         self.model, self.opt, self.grad_scale = model, opt, grad_scale
-        self._deferred_before = model.deferred_counts
-        model.deferred_counts = True                      # nothing inside the graph may wait for the host
+        self._deferred_before = (model.deferred_counts, model.deferred_max_slots)
+        model.deferred_counts, model.deferred_max_slots = True, 1 << 62     # nothing inside the graph may wait for the host
         self.col, self.prev, self.nxt = (_static_like(b, ray_grads) for b in (col, prev, nxt))
         self.batch = self._static_batch(batch)
         n_total = sum(len(b) for b in (self.col, self.prev, self.nxt) if b is not None)
@@ -181,4 +181,4 @@ class GraphedTrainStep:
             raise RuntimeError("captured step: a ray produced more samples than LSEOccGridEstimator._cap_per_ray allows")
 
     def close(self):
-        self.model.deferred_counts = self._deferred_before
+        self.model.deferred_counts, self.model.deferred_max_slots = self._deferred_before

@@ -272,11 +272,13 @@ class VolumetricSampler(nn.Module):
         rays_d = ray_bundle.directions.contiguous()
         t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None else None
         t_max = ray_bundle.fars.contiguous().reshape(-1) if ray_bundle.fars is not None else None
-        return self.occupancy_grid.sampling(
+        ri, ts, te, packed, n_dev = self.occupancy_grid.sampling(
             rays_o=rays_o.detach(), rays_d=rays_d.detach(), t_min=t_min, t_max=t_max,
             sigma_fn=self.get_sigma_fn(rays_o.detach(), rays_d.detach(), ray_bundle.times),
             render_step_size=render_step_size, near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane,
             stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, deferred=True)
+        ops.fake_sample_if_empty(packed, n_dev, ri, ts, te)     # "create a single fake sample" of forward(), on the device
+        return ri, ts, te, packed, n_dev
 
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
                 alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None
@@ -329,9 +331,12 @@ class LSENeRFModel(nn.Module):
         self.kwargs = kwargs
         self.collider = None                       # enable_collider False for NGP
         # training fast path without host read-backs of the sample counts (LSEOccGridEstimator.sampling(deferred=True)); the
-        # values are those of the synchronising path bit for bit.  Off by default: buffers are sized by a proven capacity
-        # (about 3x the samples in the reference's default configuration) instead of the exact count.
-        self.deferred_counts = False
+        # values are those of the synchronising path bit for bit (tests/test_gpu_deferred.py).  Buffers are sized by a proven
+        # capacity (about 3x the samples in the reference's default configuration, 1.5x for M-march) instead of the exact
+        # count; a batch whose capacity would exceed `deferred_max_slots` packed samples takes the synchronising path.
+        self.deferred_counts = True
+        self.deferred_max_slots = 1 << 24      # (a 4-level grid marched with cone 0 has a loose bound: 8040 slots per ray -- 33 M for
+                                               #  4096 rays, whose early-exit workgroups cost 0.27 ms: measured, bench.py inside-box)
         self.populate_modules()
         self.log_losses_dict = {"log_loss": self.log_loss, "enerf_norm_loss": self.enerf_norm_loss}
         self.rgb_losses_dic = {"linspace": self.mse_loss, "deblur": self.mse_loss}
@@ -433,6 +438,13 @@ class LSENeRFModel(nn.Module):
     def correct_evs_dim(self, inp):
         return self.rgb_to_one(inp) if self.config.ev_one_dim else inp
 
+    def use_deferred_counts(self, num_rays: int) -> bool:
+        """Whether a batch of ``num_rays`` rays takes the count-free sampler path (``deferred_counts`` and the slot budget)."""
+        cfg = self.config
+        return bool(self.deferred_counts and cfg.render_step_size and cfg.render_step_size > 0 and
+                    num_rays * self.occupancy_grid._cap_per_ray(cfg.near_plane, cfg.far_plane, cfg.render_step_size,
+                                                                cfg.cone_angle) <= self.deferred_max_slots)
+
     # -- R:lse_nerf/lsenerf.py:265-326 ----------------------------------------------------------------
     def forward(self, ray_bundle: RayBundle, **kwargs):
         if self.collider is not None:
@@ -443,7 +455,7 @@ class LSENeRFModel(nn.Module):
         assert self.field is not None
         num_rays = len(ray_bundle)
         cfg = self.config
-        if self.deferred_counts and self.training and self.sampler._packed_field is self.field and cfg.render_step_size > 0:
+        if self.training and self.sampler._packed_field is self.field and self.use_deferred_counts(num_rays):
             # no sample count visits the host: capacity-extent arrays + a device-side count handed to every per-sample kernel
             ri, ts, te, packed, n_dev = self.sampler.sample_packed(
                 ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,

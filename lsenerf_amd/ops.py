@@ -236,6 +236,14 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
 
 
 @torch.no_grad()
+def fake_sample_if_empty(packed_info, n_dev, ray_indices, t_starts, t_ends):
+    """nerfstudio's single fake sample (ray 0, t = 1) when the device-side count is 0 (lse_fake_sample_if_empty); in place."""
+    _lib.call("lse_fake_sample_if_empty", _chk(packed_info, torch.int64, "packed_info"), packed_info.shape[0],
+              _chk(n_dev, torch.int64, "n_dev"), _chk(ray_indices, torch.int32, "ray_indices"), _f32(t_starts, "t_starts"),
+              _f32(t_ends, "t_ends"), _stream())
+
+
+@torch.no_grad()
 def visibility_compact_deferred(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps: float, alpha_thre: float,
                                 from_alpha: bool = False, alpha_cap: Optional[torch.Tensor] = None):
     """``visibility_compact`` with the survivors' count left on the device: outputs keep the inputs' capacity.

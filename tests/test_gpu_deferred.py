@@ -48,6 +48,8 @@ def test_deferred_counts_equal_the_synchronising_path(case):
                    metadata={"appearance_id": torch.randint(0, 16, (R,), generator=g).cuda()})
     jit, target = torch.rand(R, generator=g).cuda(), torch.rand(R, 3, generator=g).cuda()
     ops.SYNC_STATS.update(seconds=0.0, count=0)
+    assert m.deferred_counts is True            # the model's default
+    m.deferred_counts = False
     out_s, g_s, l_s = _step(m, rb, jit, target)
     n_sync = ops.SYNC_STATS["count"]
     assert n_sync == 2          # marcher count + survivors of the cull (early_stop_eps > 0 keeps the pre-pass on in both cases)
@@ -76,8 +78,8 @@ def test_deferred_counts_equal_the_synchronising_path(case):
 
 
 def test_deferred_counts_with_no_sample_at_all_and_capacity_bound():
-    """Every ray misses every occupied cell: the device-side count is 0, every per-sample kernel leaves at once, the renders are
-    zero and the gradients vanish -- nothing reads the (uninitialised) capacity buffers.  And the capacity is what
+    """Every ray misses every occupied cell: the device-side count is 0, nerfstudio's single fake sample is inserted on the device,
+    the renders equal the synchronising path's and the gradients vanish -- nothing reads the (uninitialised) capacity buffers.  And the capacity is what
     _cap_per_ray promises: never smaller than the count of the synchronising path, for cone and constant steps."""
     from lsenerf_amd import RayBundle
     m = _model()
@@ -89,7 +91,13 @@ def test_deferred_counts_with_no_sample_at_all_and_capacity_bound():
                    camera_indices=torch.zeros(R, 1, dtype=torch.long, device="cuda"),
                    metadata={"appearance_id": torch.zeros(R, dtype=torch.long, device="cuda")})
     out = m.exec_get_outputs(rb)
-    assert int(out["num_samples_per_ray"].sum()) == 0 and float(out["rgb"].abs().max()) == 0.0
+    # (nerfstudio's single fake sample -- ray 0, t_start = t_end = 1, weight 0 -- is inserted on the device: lse_fake_sample_if_empty)
+    assert out["num_samples_per_ray"].tolist() == [1] + [0] * (R - 1) and float(out["rgb"].detach().abs().max()) == 0.0
+    m.deferred_counts = False
+    out_s = m.exec_get_outputs(rb)
+    m.deferred_counts = True
+    for k in ("num_samples_per_ray", "rgb", "accumulation", "depth"):
+        assert torch.equal(out[k], out_s[k]), k
     out["rgb"].sum().backward()
     assert float(m.field.mlp_base_grid.params.grad.abs().max()) == 0.0
     # capacity bound against fully occupied grids (the worst case for the count)

@@ -101,4 +101,4 @@ def test_graphed_step_equals_eager_step(ray_grads):
     with pytest.raises(ValueError, match="fixed"):
         step(bundles[0], None, None, batch, jitter=jit)
     step.close()
-    assert m_g.deferred_counts is False
+    assert m_g.deferred_counts is True and m_g.deferred_max_slots == 1 << 24
