@@ -102,3 +102,62 @@ def test_graphed_step_equals_eager_step(ray_grads):
         step(bundles[0], None, None, batch, jitter=jit)
     step.close()
     assert m_g.deferred_counts is True and m_g.deferred_max_slots == 1 << 24
+
+
+def test_graphed_step_feeds_a_pose_optimiser_outside_the_graph():
+    """BASELINE config 4 with the captured step: the spline camera optimiser turns pixel samples into 4 virtual-camera rays per
+    pixel OUTSIDE the graph (eager torch code, R:lse_nerf/ns_camera_optimizer.py), the graph renders them, averages the 4 renders
+    per pixel (deblur), back-propagates to the rays, and ``step.ray_grads`` continues the backward pass eagerly into the pose
+    parameters.  The control-tangent gradients must equal those of the fully eager step."""
+    import numpy as np
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle, cameras as cam
+    from lsenerf_amd.graph import GraphedTrainStep
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    from tests.test_cameras_cpu import gen_data
+    torch.manual_seed(96)
+    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, rgb_loss_type="deblur", use_mapping=False)
+    base = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 6)
+    with torch.no_grad():
+        base.field.mlp_base_grid.params.mul_(300.0)
+    c2w, ts = gen_data(6, max_t=1.0, seed=2)
+    c2w[:, :3, 3] *= 0.3
+    g = torch.Generator().manual_seed(1)
+    n_px = 48
+    ci = torch.randint(1, 5, (n_px,), generator=g).cuda()
+    coords = torch.randint(0, 32, (n_px, 2), generator=g).float().cuda()
+    gt = torch.rand(n_px, 3, generator=g).cuda()
+    jit = torch.rand(n_px * 4, generator=g).cuda()
+    grads = []
+    for graphed in (False, True):
+        m = copy.deepcopy(base).cuda().train()
+        m.occupancy_grid.binaries.copy_(random_binaries(2, 32, 0.5, 3).cuda())
+        m.occupancy_grid.occs.copy_(m.occupancy_grid.binaries.flatten().float() * 0.5)
+        opt = FlatAdam(FlatParams(m.get_param_groups()["fields"]), lr=1e-2, eps=1e-15)
+        cams = cam.EdCameras(torch.from_numpy(c2w), 60.0, 60.0, 16.0, 16.0, 32, 32, times=torch.from_numpy(ts))
+        spl = cam.CameraOptimizerConfig(mode="SO3xR3", optim_type="spline", exp_t=0.05).setup(num_cameras=6, device="cpu", cameras=cams,
+                                                                                              dM=torch.eye(4)).to("cuda")
+        spl.device = "cuda"
+        cams.times = cams.times.cuda()
+        rb = cam.generate_deblur_rays(cams, spl, ci, coords)                      # differentiable w.r.t. the spline's control tangents
+        rb.metadata.setdefault("appearance_id", torch.zeros(len(rb), dtype=torch.long, device="cuda"))
+        batch = {"col_batch": {"image": gt}, "evs_batch": None}
+        if graphed:
+            step = GraphedTrainStep(m, opt, rb, None, None, batch, ray_grads=True, jitter="input")
+            loss = step(rb, None, None, batch, jitter=jit)["rgb_loss"]
+            g_o, g_d = step.ray_grads["col"]
+            torch.autograd.backward([rb.origins, rb.directions], [g_o, g_d])         # ... and on into the pose parameters, eagerly
+            table_grad = opt.flat.grad.clone()
+        else:
+            opt.zero_grad()
+            _, losses, _ = m.train_step_bundles(rb, None, None, batch, jitter=jit)
+            loss = losses["rgb_loss"]
+            loss.backward()
+            table_grad = opt.flat.grad.clone()
+        pose = [p.grad.clone() for p in spl.parameters() if p.grad is not None]
+        assert pose and all(float(p.abs().max()) > 0 for p in pose)
+        grads.append((float(loss), pose, table_grad))
+    (l0, p0, t0), (l1, p1, t1) = grads
+    assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0))
+    assert nmax_err(t1, t0, 1e-12) < 3e-5
+    for a, b in zip(p1, p0):
+        assert nmax_err(a, b, 1e-12) < 1e-4
