@@ -366,7 +366,6 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
     if (MODE == 2 && lane == 0 && n_samples > cap32) atomicOr(a.overflow, 1);
 }
 
-// single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
 // nerfstudio's VolumetricSampler inserts ONE fake sample (ray 0, t_start = t_end = 1) when no ray produced any, so that nothing
 // downstream sees empty tensors; with the count on the device the same rule is applied there
 __global__ void fake_sample_kernel(int64_t *__restrict__ packed, int64_t *__restrict__ n_dev, int32_t *__restrict__ ri,
@@ -382,6 +381,7 @@ __global__ void fake_sample_kernel(int64_t *__restrict__ packed, int64_t *__rest
     }
 }
 
+// single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
 __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t *__restrict__ cnts, int n, int64_t *packed,
                                                          int64_t *total)
 {
