@@ -205,6 +205,7 @@ typedef struct lse_hash_bwd_opts {
     int32_t replicas, replica_levels;
     void *workspace;            /* device memory, zero on entry, zero again when the call's kernels have run; NULL = no replicas */
     int64_t workspace_bytes;
+    int32_t prefetch;           /* gran 6: fetch level l+1's dy / table operands before level l's cache pass (see hashgrid.hip) */
 } lse_hash_bwd_opts;
 void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
 /* bytes of `workspace` that lse_hash_bwd_ex needs for opts->replicas x the levels below opts->replica_levels (NULL = defaults) */

@@ -27,7 +27,8 @@ class GridDesc(Structure):
 class HashBwdOpts(Structure):
     _fields_ = [("impl", c_int32), ("gran", c_int32), ("few_runs", c_int32), ("second_probe", c_int32), ("rounds", c_int32),
                 ("dbg", c_int32), ("interleave_from_scale", c_float), ("stage_max", c_int32), ("coarse_levels", c_int32),
-                ("replicas", c_int32), ("replica_levels", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+                ("replicas", c_int32), ("replica_levels", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+                ("prefetch", c_int32)]
 
 
 class EpilogueDesc(Structure):

@@ -717,7 +717,13 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // instructions: the list is stored trip-major transposed, so the 4 slots a lane group handles in a trip are one 8-byte read;
 // the payload is read AND zeroed by one ds_wrxchg_rtn_b32; the keys are reset in bulk after the last trip (2 x ds_write_b128
 // per lane).  Per 32 slots: 1 + 4 + 4 = 9 instead of 20 DS instructions, per pass ~75 instead of ~140 in the flush.
-template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false>
+// kPrefetch (round 3): vmcnt retires in order, and a no-return atomic stays counted for ~3000 cycles when every CU is issuing them
+// (MI355X_MICROARCH.md).  A level's dy load and table gathers, issued at the top of the level right behind the previous level's
+// flush atomics, can therefore not be consumed before those atomics have retired: every level begins with that wait.  With
+// kPrefetch the loads of level l+1 are issued right after the scan of level l -- BEFORE level l's cache pass -- and are waited for
+// just before the pass sends its first atomic (an empty asm that consumes the registers places the s_waitcnt there): by then they
+// have had the whole insert phase to arrive, and the atomics get the whole next level to retire.
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -780,6 +786,40 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 #pragma unroll
     for (int k = 0; k < 16; ++k) q_v[k] = 0.f;
     int fill = 0;
+
+    // (kPrefetch) level l+1's operands, fetched while level l's cache pass runs
+    float nw0 = 0.f, nw1 = 0.f, nw2 = 0.f;
+    uint32_t np0 = 0, np1 = 0, np2 = 0, nidx[8];
+    float2 ngy = make_float2(0.f, 0.f), ntv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        nidx[c] = 0u;
+        ntv[c] = make_float2(0.f, 0.f);
+    }
+    bool pending_touch = false;     // wave-uniform: loads of the next level are in flight and not yet waited for
+    auto fetch_next = [&](int l) {
+        const LevelInfo nli = level_info(g, l);
+        pos_fract(px[0][0], nli.scale, nw0, np0);
+        pos_fract(px[0][1], nli.scale, nw1, np1);
+        pos_fract(px[0][2], nli.scale, nw2, np2);
+        ngy = dy[(int64_t)l * n_cap + si[0]];
+        corner_indices(nli, np0, np1, np2, nidx);
+        if (WITH_DX) {
+            const float2 *__restrict__ ntab = table + nli.offset;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ntv[c] = ntab[nidx[c]];
+        }
+        pending_touch = true;
+    };
+    auto touch_next = [&]() {
+        if (!kPrefetch || !pending_touch) return;
+        asm volatile("" ::"v"(ngy.x), "v"(ngy.y));
+        if (WITH_DX) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(ntv[c].x), "v"(ntv[c].y));
+        }
+        pending_touch = false;
+    };
 
     auto insert_pass = [&](const bool act, const uint32_t (&gi)[8], const float (&vv)[16]) {
         uint32_t used = 0;   // occupied cache slots (wave-uniform)
@@ -871,6 +911,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 // written by a PAIR of lanes in one instruction (lane and lane^1 swap operands through DPP), so the
                 // 8 bytes cost one request to the atomic units instead of two.
                 const bool is_odd = lane & 1;
+                touch_next();      // (kPrefetch) the next level's loads are consumed before this pass's first atomic
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (__builtin_amdgcn_ballot_w64(to_mem[c]) == 0) continue;
@@ -907,6 +948,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             if constexpr (kFlush2) {
                 static_assert(!kFlush2 || (kPair && kPay == 8 && kSlots == 512), "flush v2: 512 paired 32-byte slots");
                 const uint32_t gq = (uint32_t)lane >> 3;
+                touch_next();
                 for (uint32_t t0 = 0; t0 < used; t0 += 32) {
                     const uint64_t four = *(lds_u64 *)&list[t0 + 4 * gq];
                     uint32_t sl[4], ln[4];
@@ -964,6 +1006,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         __builtin_amdgcn_wave_barrier();
     };
 
+    if (kPrefetch && g.l_begin < g.l_end) fetch_next(g.l_begin);
     for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
         // (few-runs path only)  The coarsest levels are a few thousand lines that every wave of the launch adds to: the
@@ -978,18 +1021,31 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         for (int r = 0; r < kRounds; ++r) {
             float w0, w1, w2;
             uint32_t p0, p1, p2;
-            pos_fract(px[r][0], li.scale, w0, p0);
-            pos_fract(px[r][1], li.scale, w1, p1);
-            pos_fract(px[r][2], li.scale, w2, p2);
-            float2 gy = dy[(int64_t)l * n_cap + si[r]];
-            if (!valid[r]) gy = make_float2(0.f, 0.f);
+            float2 gy;
             uint32_t idx[8];
-            corner_indices(li, p0, p1, p2, idx);
             float2 tv[8];
-            if (WITH_DX) {
+            if constexpr (kPrefetch) {      // fetched during the previous level's cache pass (or by the prologue)
+                w0 = nw0; w1 = nw1; w2 = nw2;
+                p0 = np0; p1 = np1; p2 = np2;
+                gy = ngy;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
+                for (int c = 0; c < 8; ++c) {
+                    idx[c] = nidx[c];
+                    tv[c] = ntv[c];
+                }
+                pending_touch = false;
+            } else {
+                pos_fract(px[r][0], li.scale, w0, p0);
+                pos_fract(px[r][1], li.scale, w1, p1);
+                pos_fract(px[r][2], li.scale, w2, p2);
+                gy = dy[(int64_t)l * n_cap + si[r]];
+                corner_indices(li, p0, p1, p2, idx);
+                if (WITH_DX) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) tv[c] = tab[idx[c]];
+                }
             }
+            if (!valid[r]) gy = make_float2(0.f, 0.f);
             // runs of lanes in the same cell
             const uint32_t q0 = wave_shr1(p0), q1 = wave_shr1(p1), q2 = wave_shr1(p2);
             const int head = (lane == 0) || (q0 != p0) || (q1 != p1) || (q2 != p2);
@@ -1032,6 +1088,9 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 dacc[r][1] = fmaf(li.scale, d1, dacc[r][1]);
                 dacc[r][2] = fmaf(li.scale, d2, dacc[r][2]);
             }
+            if constexpr (kPrefetch) {
+                if (l + 1 < g.l_end) fetch_next(l + 1);      // the next level's loads go out before this level's cache pass
+            }
             // ---- run ends add their 8 corner sums into the line cache, then the level's lines are flushed.
             // The kernel is instruction-issue bound (rocprof: VALU+SALU+LDS issue ~ 3 ms of a 3.6 ms launch), so this part
             // is written for few instructions: one probe per corner, no retry rounds (a lost slot goes straight to memory),
@@ -1057,6 +1116,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const int k16 = lane & 15;
+                    touch_next();
                     for (int r0 = lane >> 4; r0 < n_ends; r0 += 4) {
                         const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
                         const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
@@ -1335,6 +1395,7 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     o->replica_levels = 4; // 16^3 .. 43^3: 125 568 entries = 1 MB per replica
     o->workspace = nullptr;
     o->workspace_bytes = 0;
+    o->prefetch = 0;
 }
 
 static int64_t replica_floats(const lse_grid_desc *desc, const lse_hash_bwd_opts &o, int *levels_out)
@@ -1456,6 +1517,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            return lse::check_launch("lse_hash_bwd");
+        }
+        if (o.gran == 6 && o.prefetch) {      // ... and the next level's operands fetched ahead of the cache pass
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }

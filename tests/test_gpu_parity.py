@@ -336,7 +336,10 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 # coarse-level replicas (default: 8 replicas of levels 0-3): off, more of them, every dense level, with the coarse kernel
                 "no_replicas": {"replicas": 0}, "replicas8": {"replicas": 8}, "replicas32_levels6": {"replicas": 32, "replica_levels": 6},
                 "replicas_coarse_kernel": {"coarse_levels": 7, "replicas": 16, "replica_levels": 5},
-                "replicas_few_runs16": {"few_runs": 16, "replica_levels": 16, "replicas": 4}}
+                "replicas_few_runs16": {"few_runs": 16, "replica_levels": 16, "replicas": 4},
+                # next level's dy / table operands fetched before the current level's cache pass
+                "prefetch": {"prefetch": 1}, "prefetch_no_few_runs": {"prefetch": 1, "few_runs": 0}, "prefetch_stage_all": {"prefetch": 1, "stage_max": 64},
+                "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
     for sc in meta.scales:
