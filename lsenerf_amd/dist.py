@@ -8,10 +8,11 @@ Occupancy grids stay replicated without DDP's per-forward buffer broadcast: ``LS
 cells and jitter from its OWN generator, re-seeded from ``(base seed, step)`` at every update, so every rank (whatever
 its global seed, R:train.py:104 seeds by rank) refreshes the same cells with the same positions from the same
 parameters; ``check_grid_consistency`` asserts it (rehearsed in tools/dp_rehearsal.py and tests/test_dist_cpu.py).
-"The same parameters give the same densities" holds to the last bit on one GPU in a quiet process; with several processes
-sharing a GPU the rehearsal saw ~0.3 % of the refreshes differ in the last bits of a few hash features, so
-``attach_grid_sync`` additionally broadcasts rank 0's ``occs`` / ``binaries`` after every refresh (33.5 + 8.4 MB once per 16
-steps: what DDP's buffer broadcast does on every forward, R:lse_nerf/lse_pipeline.py:97).
+"The same parameters give the same densities" holds to the last bit with one process per GPU (the production layout; every
+refresh of the round-3 rehearsal agrees across ranks before any broadcast).  ``attach_grid_sync`` additionally broadcasts rank 0's
+``occs`` / ``binaries`` after every refresh (33.5 + 8.4 MB once per 16 steps: what DDP's buffer broadcast does on every forward,
+R:lse_nerf/lse_pipeline.py:97), so that a divergence -- round 2 saw one with two processes' kernels interleaved on ONE card,
+DESIGN.md section 7 -- cannot persist.
 
 Backend-agnostic: the same code runs on gloo/CPU tensors, which is how the world_size-2 tests exercise it.
 """
@@ -166,20 +167,37 @@ class ShardedAdamExchange:
 
     def step(self):
         """Call after backward(): exchanges gradients, updates this rank's shard, replicates the parameters."""
-        g, p = self.flat.grad, self.flat.data
-        lo, hi = self.rank * self.per, (self.rank + 1) * self.per
+        self.start()
+        self.finish()
+
+    def start(self):
+        """First half: launch the gradient exchange (reduce-scatter; all-reduce on backends without one) asynchronously.
+        ``finish`` waits for it, runs Adam on this rank's shard and all-gathers the parameters -- dist.GradPipeline puts the
+        next step's ray marcher between the two."""
+        assert getattr(self, "_work", None) is None and not getattr(self, "_started", False), "start() twice without finish()"
+        g = self.flat.grad
         if self._pad:
             gp = self.grad_full
             gp[: g.numel()].copy_(g)
         else:
             gp = g
-        if self.world == 1:
+        self._gp, self._work = gp, None
+        if self.world > 1:
+            if self._native():
+                self._work = dist.reduce_scatter_tensor(self.grad_shard, gp, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                self._work = dist.all_reduce(gp, op=dist.ReduceOp.SUM, async_op=True)
+        self._started = True
+
+    def finish(self):
+        assert getattr(self, "_started", False), "finish() without start()"
+        p, gp = self.flat.data, self._gp
+        lo, hi = self.rank * self.per, (self.rank + 1) * self.per
+        if self._work is not None:
+            self._work.wait()
+        if self.world == 1 or not self._native():
             self.grad_shard.copy_(gp[lo:hi])
-        elif self._native():
-            dist.reduce_scatter_tensor(self.grad_shard, gp, op=dist.ReduceOp.SUM)
-        else:
-            dist.all_reduce(gp, op=dist.ReduceOp.SUM)
-            self.grad_shard.copy_(gp[lo:hi])
+        self._work, self._started = None, False
         pfull = self.param_full if self._pad else p
         if self._pad:
             pfull[: p.numel()].copy_(p)
@@ -211,9 +229,12 @@ class GradPipeline:
     the parameters (grid refresh, evaluation, checkpoint) and at the end of a timed region, so that exactly K optimizer
     steps and K all-reduces belong to K steps."""
 
-    def __init__(self, opt, world: Optional[int] = None):
+    def __init__(self, opt, world: Optional[int] = None, sharded: Optional["ShardedAdamExchange"] = None):
+        """``sharded``: finish the step with ``ShardedAdamExchange`` (reduce-scatter -> Adam on 1/W -> all-gather) instead of the
+        all-reduce + full Adam of ``opt``; ``opt`` then only supplies the learning-rate schedule and the step count."""
         self.opt = opt
         self.world = world if world is not None else world_size()
+        self.sharded = sharded
         self.work, self.pending = None, False
 
     def attach(self, estimator):
@@ -223,15 +244,23 @@ class GradPipeline:
     def start(self):
         """Call after backward(): launches the asynchronous all-reduce of the flat gradient buffer."""
         assert not self.pending, "GradPipeline.start() twice without flush()"
-        self.work = allreduce_grads(self.opt.flat.grad, async_op=True)
+        if self.sharded is not None:
+            self.sharded.lr = self.opt.current_lr()
+            self.sharded.start()
+        else:
+            self.work = allreduce_grads(self.opt.flat.grad, async_op=True)
         self.pending = True
 
     def flush(self):
         """wait -> Adam (mean over ranks folded into grad_scale).  No-op when nothing is in flight."""
         if self.pending:
-            if self.work is not None:
-                self.work.wait()
-            self.opt.step(grad_scale=1.0 / self.world)
+            if self.sharded is not None:
+                self.opt.step_count += 1
+                self.sharded.finish()
+            else:
+                if self.work is not None:
+                    self.work.wait()
+                self.opt.step(grad_scale=1.0 / self.world)
             self.work, self.pending = None, False
 
 

@@ -247,9 +247,14 @@ def test_overlapped_exchange_with_three_hash_backwards_per_step(tmp_path):
 class _ToyOpt:
     """FlatAdam's interface on CPU tensors (the HIP Adam kernel needs a GPU)."""
 
+    lr = 1e-2
+
     def __init__(self, flat):
         self.flat, self.step_count = flat, 0
         self.state = {"m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)}
+
+    def current_lr(self):
+        return self.lr
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -281,13 +286,14 @@ def _pipeline_worker(rank, world, port, out):
     x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
     sl = ldist.shard_rays(64, rank, world)
     finals, seen = [], []
-    for mode in ("pipelined", "plain"):
+    for mode in ("pipelined", "plain", "pipelined_sharded"):
         model = _model()
-        flat = FlatParams(model.parameters())
+        flat = FlatParams(model.parameters(), total_multiple=world * 64 if mode == "pipelined_sharded" else 1)
         ldist.broadcast_params(flat.data)
         opt = _ToyOpt(flat)
         est = _ToyEstimator()
-        pipe = ldist.GradPipeline(opt, world).attach(est) if mode == "pipelined" else None
+        sharded = ldist.ShardedAdamExchange(flat, lr=opt.lr, adam_fn=_adam_fn_cpu) if mode == "pipelined_sharded" else None
+        pipe = ldist.GradPipeline(opt, world, sharded=sharded).attach(est) if mode != "plain" else None
         for step in range(4):
             # the visibility pre-pass reads the parameters: it must see the update of the previous step
             seen.append(est.sampling(lambda: float(flat.data.sum())))
@@ -314,7 +320,12 @@ def test_grad_pipeline_is_value_identical_to_the_blocking_exchange(tmp_path):
     mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
     assert torch.equal(got["finals"][0], got["finals"][1])
-    assert got["seen"][:4] == got["seen"][4:]          # sigma_fn saw the same parameters in both schedules
+    assert got["seen"][:4] == got["seen"][4:8]         # sigma_fn saw the same parameters in both schedules
+    # GradPipeline over ShardedAdamExchange (reduce-scatter started behind backward, Adam on 1/W + all-gather behind the next
+    # step's marcher): the same parameters up to the summation order of the sharded reduction
+    n = got["finals"][1].numel()
+    assert torch.allclose(got["finals"][2][:n], got["finals"][1], rtol=0, atol=1e-6)
+    assert all(abs(a - b) < 1e-4 for a, b in zip(got["seen"][8:], got["seen"][4:8]))
 
 
 def _sharded_inplace_worker(rank, world, port, out):
