@@ -476,6 +476,8 @@ def main():
         ldist.attach_grid_sync(model.occupancy_grid)      # fully occupied and never refreshed, the hook is part of the template
     if mode == "pipelined":
         pipeline = ldist.GradPipeline(opt, world).attach(model.occupancy_grid)
+    if mode == "pipelined_sharded":     # reduce-scatter behind backward, Adam on 1/W + all-gather behind the next step's marcher
+        pipeline = ldist.GradPipeline(opt, world, sharded=ldist.ShardedAdamExchange(flat, lr=1e-2, eps=1e-15)).attach(model.occupancy_grid)
     if mode in ("overlap", "split"):
         grid = model.field.mlp_base_grid
         exchange = ldist.OverlappedGradExchange(flat, grid.params, grid.meta.offsets, split_level=min(6, grid.meta.n_levels - 1))
