@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int kMaxLevels = LSE_MAX_OCC_LEVELS;
-constexpr int kBatch = 16;   // DDA cells looked ahead per batch (occupancy loads in flight)
+constexpr int kBatch = 32;   // DDA cells looked ahead per batch (occupancy loads in flight); 16 until round 3
 
 struct TraverseArgs {
     const float *rays_o, *rays_d;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             // lane b fetches the occupancy byte of look-ahead cell b: one load instruction for the whole batch
             __syncthreads();
             const bool my_occ = (lane < nb) ? (a.binaries[s_cell[lane]] != 0) : false;
-            const uint32_t occ_mask = (uint32_t)__ballot(my_occ);
+            const uint64_t occ_mask = __ballot(my_occ);
 
             if (a.step_size <= 0.0f) {
                 for (int b = 0; b < nb; ++b) {   // one interval per occupied cell
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                         // A run of unoccupied cells is left where its LAST cell is left: the cell boundaries increase along
                         // the ray and an unoccupied cell only advances t while t + dt/2 < boundary, so stepping cell by cell
                         // and stepping against the run's last boundary perform the same additions in the same order.
-                        const uint32_t rest = occ_mask >> b;
-                        const int run = rest ? min((int)__builtin_ctz(rest), nb - b) : nb - b;
+                        const uint64_t rest = occ_mask >> b;
+                        const int run = rest ? min((int)__builtin_ctzll(rest), nb - b) : nb - b;
                         b += run - 1;
                     }
                     const float t_traverse = s_tt[b];
