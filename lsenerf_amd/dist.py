@@ -288,6 +288,9 @@ def sync_grid(estimator, src: int = 0) -> None:
     dist.broadcast(b8, src=src)
     if hasattr(estimator, "_occ_mean_host"):
         estimator._occ_mean_host = None
+    if "_occ_mean_dev" in getattr(estimator, "__dict__", {}):      # device-side copy of occs.mean() (count-free sampler path)
+        estimator.__dict__["_occ_mean_dev_version"] = None
+        estimator._occ_mean_device()
 
 
 def attach_grid_sync(estimator, src: int = 0):

@@ -278,6 +278,11 @@ class LSEOccGridEstimator(nn.Module):
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre).reshape(1).contiguous()
         ops.occ_binarize(self.occs, thre, self._binaries_u8().view(-1))
         self._occ_mean_host = None
+        # the HIP kernels write `occs` through its raw pointer (no tensor version bump): refresh the device-side mean explicitly,
+        # now and in place -- a captured step reads that buffer at its fixed address
+        if "_occ_mean_dev" in self.__dict__:
+            self.__dict__["_occ_mean_dev_version"] = None
+            self._occ_mean_device()
         hook = getattr(self, "after_update_hook", None)      # data parallel: dist.attach_grid_sync
         if hook is not None:
             hook()

@@ -25,7 +25,8 @@ def _setup(ray_grads):
     for _ in range(2):
         m = copy.deepcopy(base).cuda().train()
         m.occupancy_grid.binaries.copy_(random_binaries(2, 32, 0.5, 3).cuda())
-        m.occupancy_grid.occs.copy_(m.occupancy_grid.binaries.flatten().float() * 0.5)
+        # occs.mean() = 0.006 < alpha_thre = 0.01: the cap `min(alpha_thre, occs.mean())` is the ACTIVE threshold of the culling
+        m.occupancy_grid.occs.copy_(m.occupancy_grid.binaries.flatten().float() * 0.012)
         flat = FlatParams(m.get_param_groups()["fields"])
         models.append(m)
         opts.append(FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=50))     # a schedule that moves visibly
@@ -72,6 +73,11 @@ def test_graphed_step_equals_eager_step(ray_grads):
         if it == 2:                      # an occupancy refresh between replays: in place, outside the graph
             for m in (m_e, m_g):
                 m.update_occupancy_grid(0)
+            # the refresh writes `occs` through raw pointers; the device-side copy of occs.mean() (the cap of the alpha threshold)
+            # must follow it: here the mean drops below alpha_thre = 0.01, so a stale cap would change the culling
+            mean_now = float(m_g.occupancy_grid.occs.mean())
+            assert 0.0 < mean_now < 0.01 and abs(mean_now - 0.006) > 1e-5            # the refresh moved it
+            assert float(m_g.occupancy_grid.__dict__["_occ_mean_dev"]) == mean_now    # (read as is: no recomputation here)
         bundles, batch, jit = batch_of(60 + 10 * it)
         sync_before = ops.SYNC_STATS["count"]
         l_g = {k: v for k, v in step(*bundles, batch, jitter=jit).items()}
