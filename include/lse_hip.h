@@ -182,7 +182,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size);
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
  *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
- *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 4)
+ *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
  *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)

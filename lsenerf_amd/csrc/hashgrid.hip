@@ -723,7 +723,10 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // kPrefetch the loads of level l+1 are issued right after the scan of level l -- BEFORE level l's cache pass -- and are waited for
 // just before the pass sends its first atomic (an empty asm that consumes the registers places the s_waitcnt there): by then they
 // have had the whole insert phase to arrive, and the atomics get the whole next level to retire.
-template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false>
+// kAlign (round 3): the two sectors of a line leave as ONE request only when their list entries sit in neighbouring lane groups of the
+// SAME flush instruction; in slot order a sibling pair straddles an 8-entry boundary one time in eight.  With kAlign every occupied
+// pair bucket takes an even-aligned pair of list positions (an absent sibling is an idle entry), so a line is never split.
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -931,12 +934,14 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 #pragma unroll
                 for (int s0 = 0; s0 < kSlots; s0 += 64) {
                     const bool occ = key[s0 + lane] != kNoLine;
-                    const uint64_t om = __builtin_amdgcn_ballot_w64(occ);
-                    if (occ) {
+                    // kAlign: both slots of an occupied pair bucket (lanes 2b, 2b + 1) take a list position
+                    const bool take = kAlign ? (occ || quad_swap1((int)occ) != 0) : occ;
+                    const uint64_t om = __builtin_amdgcn_ballot_w64(take);
+                    if (take) {
                         uint32_t pos = used + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
                         // trip-major transposed: list position i of trip i / 32 is handled by lane group i % 8 as its (i % 32) / 8-th slot
                         if constexpr (kFlush2) pos = (pos & ~31u) + ((pos & 7u) << 2) + ((pos >> 3) & 3u);
-                        list[pos] = (uint16_t)(s0 + lane);
+                        list[pos] = occ ? (uint16_t)(s0 + lane) : (uint16_t)0xFFFFu;      // 0xFFFF: the absent sibling of a pair
                     }
                     used += __builtin_popcountll(om);
                 }
@@ -956,8 +961,9 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     bool ok[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        ok[u] = t0 + 8 * u + gq < used;
-                        sl[u] = ok[u] ? (uint32_t)(four >> (16 * u)) & 0xFFFFu : (uint32_t)lane;
+                        const uint32_t e = (uint32_t)(four >> (16 * u)) & 0xFFFFu;
+                        ok[u] = t0 + 8 * u + gq < used && (!kAlign || e != 0xFFFFu);
+                        sl[u] = ok[u] ? e : (uint32_t)lane;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) ln[u] = key[sl[u]];
@@ -1383,7 +1389,8 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     o->stage_max = 16;     // impl 2: a level ending more runs than this per wave passes unstaged when the queue is empty
     o->gran = 6;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line, second-generation flush (4 = first-generation
                            // flush, 2 = unpaired); impl 1: 2 / 3
-    o->few_runs = 4;       // tuned on MI355X: 4..8 equal, 16 already slower
+    o->few_runs = 6;       // round 3 (replicas took the contention out of the direct adds): default configuration 1.60 -> 1.53 ms,
+                           // M-march 2.62 -> 2.62, M-packed 3.17 -> 3.20; 8: 1.51 / 2.63 / 3.28; 16: slower everywhere
     o->second_probe = 1;   // extra probe rounds (next slot) before a corner goes to memory alone; pays wherever the kernel is
                            // bound by atomic requests (sphere rays 4.27 -> 3.86 ms), costs ~2 % where it is issue-bound
     o->rounds = 32;
@@ -1437,7 +1444,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     if (opts) o = *opts;
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 6, "lse_hash_bwd: opts.gran must be 2 .. 6");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 7, "lse_hash_bwd: opts.gran must be 2 .. 7");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1517,6 +1524,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            return lse::check_launch("lse_hash_bwd");
+        }
+        if (o.gran == 7) {      // gran 6 with pair-aligned flush lists (a line is never split between two flush instructions)
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }

@@ -339,7 +339,10 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "replicas_few_runs16": {"few_runs": 16, "replica_levels": 16, "replicas": 4},
                 # next level's dy / table operands fetched before the current level's cache pass
                 "prefetch": {"prefetch": 1}, "prefetch_no_few_runs": {"prefetch": 1, "few_runs": 0}, "prefetch_stage_all": {"prefetch": 1, "stage_max": 64},
-                "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5}}
+                "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5},
+                # pair-aligned flush lists
+                "few_runs8": {"few_runs": 8},
+                "aligned_pairs": {"gran": 7}, "aligned_pairs_stage_all": {"gran": 7, "stage_max": 64}, "aligned_pairs_probe0": {"gran": 7, "second_probe": 0}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
     for sc in meta.scales:
