@@ -4,6 +4,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import pytest
@@ -56,20 +57,29 @@ def _launch_dp_rehearsal(config):
     try:
         print("\n[conftest] 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py) ...", flush=True)
         with open(log, "w") as lf:
-            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                 start_new_session=True)
+            # watchdog: the rehearsal takes 10 - 60 s; a launch that has not finished after 6 minutes (rendezvous stuck, a rank
+            # lost) is killed as a group -- the report tests then fail, the rest of the GPU tier still runs
+            def _kill():
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+            dog = threading.Timer(360.0, _kill)
+            dog.daemon = True
+            dog.start()
             try:
                 for line in p.stdout:              # tee: terminal + log file
                     lf.write(line)
                     if line.startswith("[dp_rehearsal]") or "Error" in line or "dp_rehearsal:" in line:
                         print("  " + line.rstrip(), flush=True)
-                    if time.time() - t0 > 900:
-                        p.kill()
-                        lf.write("\n[conftest] killed after 900 s\n")
-                        break
                 rc = p.wait(timeout=60)
             except subprocess.TimeoutExpired:
-                p.kill()
+                _kill()
                 rc = -9
+            finally:
+                dog.cancel()
     finally:
         if capman is not None:
             capman.resume_global_capture()
@@ -104,6 +114,9 @@ def dp_rehearsal(request):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    # the data-parallel report tests run last: under `-x` an environmental failure of the two-rank launch (ports, gloo) must not
+    # stop the parity tests that come after test_gpu_dp.py in alphabetical order
+    items.sort(key=lambda it: 1 if "test_gpu_dp" in it.nodeid else 0)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
