@@ -24,13 +24,19 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+# Run every collective of this module even in a ONE-rank process group.  With one rank each of them is the identity, so the results
+# must equal the path without torch.distributed bit for bit -- which is how the RCCL calls themselves (argument types, views into the
+# flat buffers, work handles, the bool grid through a uint8 view) are executed on a one-GPU box, where two RCCL ranks cannot share
+# the card (tools/dp_rehearsal.py --backend nccl, tests/test_gpu_dp.py).  Off in production: a single GPU needs no process group.
+SINGLE_RANK_COLLECTIVES = False
+
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun contract).  Returns (rank, world, local)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -43,6 +49,12 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def _active() -> bool:
+    """True when the collectives of this module run: a process group exists and has more than one rank (or
+    SINGLE_RANK_COLLECTIVES asks for them in a one-rank group)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES)
+
+
 def shard_rays(n_rays_global: int, rank: int, world: int) -> slice:
     """Rank r takes rays [r*R/W, (r+1)*R/W)."""
     assert n_rays_global % world == 0, f"{n_rays_global} rays do not split evenly over {world} ranks"
@@ -52,7 +64,7 @@ def shard_rays(n_rays_global: int, rank: int, world: int) -> slice:
 
 def allreduce_grads(flat_grad: torch.Tensor, async_op: bool = False):
     """Sum-all-reduce of the flat gradient buffer; returns the work handle when async."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return None
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -107,13 +119,13 @@ class OverlappedGradExchange:
         self._seen += 1
         if self._seen < self._expected:
             return          # later hash backwards still add to this slice
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _active():
             self._works.append(dist.all_reduce(self.flat.grad[self.lo:self.hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Call after backward(): exchanges what the first part did not cover and waits for everything."""
         seen, self._seen = self._seen, 0
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not _active():
             self._works.clear()
             return
         g = self.flat.grad
@@ -163,7 +175,7 @@ class ShardedAdamExchange:
         self.adam_fn = adam_fn          # (param, grad, m, v, lr, b1, b2, eps, step, grad_scale) -> None, in place
 
     def _native(self) -> bool:
-        return dist.is_initialized() and self.world > 1 and dist.get_backend() == "nccl"
+        return _active() and dist.get_backend() == "nccl"
 
     def step(self):
         """Call after backward(): exchanges gradients, updates this rank's shard, replicates the parameters."""
@@ -182,7 +194,7 @@ class ShardedAdamExchange:
         else:
             gp = g
         self._gp, self._work = gp, None
-        if self.world > 1:
+        if _active():
             if self._native():
                 self._work = dist.reduce_scatter_tensor(self.grad_shard, gp, op=dist.ReduceOp.SUM, async_op=True)
             else:
@@ -195,7 +207,7 @@ class ShardedAdamExchange:
         lo, hi = self.rank * self.per, (self.rank + 1) * self.per
         if self._work is not None:
             self._work.wait()
-        if self.world == 1 or not self._native():
+        if not self._native():
             self.grad_shard.copy_(gp[lo:hi])
         self._work, self._started = None, False
         pfull = self.param_full if self._pad else p
@@ -205,7 +217,7 @@ class ShardedAdamExchange:
         self.step_count += 1
         self.adam_fn(shard, self.grad_shard, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                      self.step_count, 1.0 / self.world)
-        if self.world > 1:
+        if _active():
             if self._native():
                 dist.all_gather_into_tensor(pfull, shard.clone())
             else:
@@ -267,7 +279,7 @@ class GradPipeline:
 def check_grid_consistency(estimator) -> bool:
     """True iff ``occs`` and ``binaries`` are bit-identical on every rank (the invariant DDP's buffer broadcast provides
     in the reference, R:lse_nerf/lse_pipeline.py:97)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return True
     ok = True
     for buf in (estimator.occs, estimator.binaries.to(torch.uint8)):
@@ -281,7 +293,7 @@ def check_grid_consistency(estimator) -> bool:
 
 def sync_grid(estimator, src: int = 0) -> None:
     """Rank ``src``'s occupancy state replaces every other rank's (``occs`` fp32, ``binaries`` bool)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return
     dist.broadcast(estimator.occs, src=src)
     b8 = estimator.binaries.view(torch.uint8) if estimator.binaries.dtype == torch.bool else estimator.binaries
@@ -301,12 +313,12 @@ def attach_grid_sync(estimator, src: int = 0):
 
 def broadcast_params(flat_data: torch.Tensor, src: int = 0):
     """Initial parameter replication (DDP's constructor broadcast)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(flat_data, src=src)
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

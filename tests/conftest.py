@@ -32,22 +32,26 @@ def _dp_test_selected(config) -> bool:
     return not files
 
 
-def _launch_dp_rehearsal(config):
-    """Two fresh child processes (torch.distributed.run, gloo, both on cuda:0) BEFORE this process makes any GPU call: ranks must
+def _launch_dp_rehearsal(config, backend="gloo"):
+    """backend "gloo": two fresh child processes (torch.distributed.run, gloo, both on cuda:0) BEFORE this process makes any GPU call: ranks must
     never be spawned from a process that has initialised the GPU.  torch.cuda.device_count() does not initialise it.
     pytest's output capture is suspended meanwhile, so the rehearsal's progress lines reach the terminal (a silent minutes-long
-    start looks like a hang to whoever runs the suite); the full log is kept for the assertion messages."""
+    start looks like a hang to whoever runs the suite); the full log is kept for the assertion messages.
+    backend "nccl": ONE fresh child process over RCCL with every collective forced (two RCCL ranks cannot share a card)."""
     import torch
     if torch.cuda.device_count() < 1:
         return {"launched": False, "reason": "no GPU visible"}
     tmp = tempfile.mkdtemp(prefix="lse_dp_")
-    out, log = os.path.join(tmp, "dp_rehearsal.json"), os.path.join(tmp, "dp_rehearsal.log")
+    out, log = os.path.join(tmp, f"dp_rehearsal_{backend}.json"), os.path.join(tmp, f"dp_rehearsal_{backend}.log")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", "dp_rehearsal.py"), "--out", out]
     env = dict(os.environ)
+    if backend == "nccl":
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "dp_rehearsal.py"), "--out", out, "--backend", "nccl"]
+        env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     capman = config.pluginmanager.getplugin("capturemanager")
     if capman is not None:
@@ -55,7 +59,7 @@ def _launch_dp_rehearsal(config):
     t0 = time.time()
     rc = None
     try:
-        print("\n[conftest] 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py) ...", flush=True)
+        print(f"\n[conftest] data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py, {backend}) ...", flush=True)
         with open(log, "w") as lf:
             p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                  start_new_session=True)
@@ -91,7 +95,7 @@ def _launch_dp_rehearsal(config):
             res["report"] = json.load(f)
         keep = os.path.join(ROOT, "gpurun_out")
         if os.path.isdir(keep):          # on the GPU box: travels back with the call
-            with open(os.path.join(keep, "dp_rehearsal_pytest.json"), "w") as f:
+            with open(os.path.join(keep, "dp_rehearsal_pytest.json" if backend == "gloo" else "dp_rehearsal_rccl_pytest.json"), "w") as f:
                 json.dump(res["report"], f, indent=1)
     return res
 
@@ -100,16 +104,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the outcome of the 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py); tests/test_gpu_dp.py asserts on it
     if not _gpu_tier_selected(config):
-        config._lse_dp_rehearsal = {"launched": False, "reason": "GPU tier not selected"}
+        config._lse_dp_rehearsal = config._lse_rccl_rehearsal = {"launched": False, "reason": "GPU tier not selected"}
     elif not _dp_test_selected(config):
-        config._lse_dp_rehearsal = {"launched": False, "reason": "subset run that does not include tests/test_gpu_dp.py"}
+        config._lse_dp_rehearsal = config._lse_rccl_rehearsal = {
+            "launched": False, "reason": "subset run that does not include tests/test_gpu_dp.py"}
     else:
         config._lse_dp_rehearsal = _launch_dp_rehearsal(config)
+        config._lse_rccl_rehearsal = _launch_dp_rehearsal(config, backend="nccl")
 
 
 @pytest.fixture(scope="session")
 def dp_rehearsal(request):
     return request.config._lse_dp_rehearsal
+
+
+@pytest.fixture(scope="session")
+def rccl_rehearsal(request):
+    return request.config._lse_rccl_rehearsal
 
 
 def pytest_collection_modifyitems(config, items):

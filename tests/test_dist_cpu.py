@@ -417,3 +417,51 @@ def test_shard_rays_rejects_uneven_splits():
     from lsenerf_amd.dist import shard_rays
     with pytest.raises(AssertionError):
         shard_rays(4097, 0, 2)
+
+
+def _single_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    calls = []
+    for name in ("all_reduce", "broadcast", "all_gather"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: lambda *a, **k: (calls.append(n), o(*a, **k))[1])(orig, name))
+    ldist.SINGLE_RANK_COLLECTIVES = True
+    assert ldist.init_from_env("gloo") == (0, 1, 0) and dist.is_initialized()      # a one-rank group IS created when forced
+    model = _model()
+    flat = FlatParams(model.parameters())
+    ldist.broadcast_params(flat.data)
+    ex = ldist.ShardedAdamExchange(flat, lr=1e-2, adam_fn=_adam_fn_cpu)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+    for _ in range(3):
+        flat.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        ldist.allreduce_grads(flat.grad.clone())
+        ex.step()
+    assert ldist.max_over_ranks(2.5, torch.device("cpu")) == 2.5
+    torch.save({"p": flat.data.clone(), "calls": calls}, out)
+    dist.destroy_process_group()
+
+
+def test_single_rank_collectives_switch_runs_every_collective_and_changes_nothing(tmp_path):
+    """dist.SINGLE_RANK_COLLECTIVES (how tests/test_gpu_dp.py executes the RCCL calls on a one-GPU box): with one rank every
+    collective is the identity, so the sharded exchange must give exactly the parameters of the loop without torch.distributed."""
+    out = str(tmp_path / "p")
+    mp.spawn(_single_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert {"all_reduce", "broadcast", "all_gather"} <= set(res["calls"])
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    assert ldist.SINGLE_RANK_COLLECTIVES is False and not ldist._active()              # off by default: no group, no collectives
+    model = _model()
+    flat = FlatParams(model.parameters())
+    ex = ldist.ShardedAdamExchange(flat, lr=1e-2, adam_fn=_adam_fn_cpu)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(64, 6, generator=g), torch.randn(64, 3, generator=g)
+    for _ in range(3):
+        flat.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        ex.step()
+    assert torch.equal(res["p"], flat.data)

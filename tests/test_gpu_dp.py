@@ -4,8 +4,11 @@ launches from pytest_configure -- before this pytest process makes its first GPU
 from a process that has initialised the GPU -- running tools/dp_rehearsal.py: 2 x 2048 rays, the reference's default
 configuration (visibility pre-pass on, 4-level 128^3 grid), occupancy refresh at steps 0 and 320, three optimizer steps, for the
 plain / pipelined / sharded / overlap exchanges of lsenerf_amd.dist, against ONE process on the full 4096-ray batch.  A one-GPU
-box cannot host two RCCL ranks, so the collectives run over gloo; the RCCL branches are exercised by bench.py --gpus N on a
-multi-GPU node.  This test only reads the report."""
+box cannot host two RCCL ranks, so the two-rank collectives run over gloo.  The RCCL calls themselves (async all_reduce on slices
+of the flat buffer, reduce_scatter_tensor / all_gather_into_tensor of the sharded Adam, broadcasts of the float and bool grids)
+are executed by a second child: ONE rank over backend "nccl" with every collective forced (dist.SINGLE_RANK_COLLECTIVES) -- each
+is then the identity, so every exchange must reproduce the single process.  Sums over several RCCL ranks run in bench.py --gpus N
+on a multi-GPU node.  These tests only read the reports."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -49,3 +52,17 @@ def test_ranks_compute_the_same_grid_without_communication(dp_rehearsal):
     rep, _ = _report(dp_rehearsal)
     for mode in MODES:
         assert rep["modes"][mode]["grids_identical_before_the_broadcast"] == [True, True], (mode, rep["modes"][mode])
+
+
+def test_rccl_calls_of_every_exchange_execute_on_hip_tensors(rccl_rehearsal):
+    """backend "nccl" (= RCCL), one rank, collectives forced: the native branches of lsenerf_amd.dist run on the MI355X."""
+    rep, r = _report(rccl_rehearsal)
+    assert rep["world"] == 1 and rep["backend"].startswith("nccl"), rep["backend"]
+    assert set(rep["modes"]) == set(MODES), r["log_tail"]
+    floor = rep["single_process"]["run_to_run_first_grad_err"]
+    for mode in MODES:
+        e = rep["modes"][mode]
+        assert e["first_step_grad_err_vs_single"] <= max(3e-6, 3 * floor), (mode, e, floor)
+        assert e["within_tolerance"] and e["samples_match_single_process"], (mode, e)
+        assert e["grids_bit_identical_across_ranks_after_refresh_step0_step320"] == [True, True], (mode, e)
+    assert rep["all_ok"], r["log_tail"]

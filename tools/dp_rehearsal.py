@@ -199,14 +199,20 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dp_rehearsal.json"))
     ap.add_argument("--modes", default="plain,pipelined,sharded,overlap")
     ap.add_argument("--concurrent", action="store_true", help="all ranks compute at the same time on the shared GPU")
+    ap.add_argument("--backend", default="gloo", help='"nccl": ONE rank over RCCL with every collective forced '
+                    "(lsenerf_amd.dist.SINGLE_RANK_COLLECTIVES): executes the RCCL calls of each exchange on HIP tensors")
     args = ap.parse_args()
     global CONCURRENT
     CONCURRENT = args.concurrent
     from lsenerf_amd import _lib, dist as ldist
-    rank, world, _ = ldist.init_from_env("gloo")
-    assert world >= 2, "launch with torch.distributed.run --nproc-per-node 2"
+    if args.backend == "nccl":
+        # two RCCL ranks cannot share one card; one rank with the collectives forced runs the same calls (each is the identity)
+        assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--backend nccl rehearses ONE rank (a one-GPU box)"
+        ldist.SINGLE_RANK_COLLECTIVES = True
+    rank, world, _ = ldist.init_from_env(args.backend)
+    assert world >= 2 or args.backend == "nccl", "launch with torch.distributed.run --nproc-per-node 2"
     global TURN_GROUP
-    TURN_GROUP = tdist.new_group(backend="gloo")
+    TURN_GROUP = tdist.new_group(backend="gloo") if world > 1 else None
     assert torch.cuda.is_available(), "the rehearsal trains the HIP model: it needs the MI355X"
     dev = torch.device("cuda", 0)                                  # all ranks share the one GPU of the box
     torch.cuda.set_device(dev)
@@ -241,7 +247,10 @@ def main():
     floor_g = grad_err(g_ref2)
     floor_p = float((ref2 - ref).abs().max())
     floor_frac = float(((ref2 - ref).abs() > 1e-6 * scale).float().mean())
-    report = {"world": world, "rays": RAYS, "steps": STEPS, "backend": "gloo (2 ranks on one MI355X)",
+    report = {"world": world, "rays": RAYS, "steps": STEPS,
+              "backend": "gloo (2 ranks on one MI355X)" if args.backend == "gloo" else
+              "nccl = RCCL, ONE rank, collectives forced (all_reduce sync + async, reduce_scatter_tensor, all_gather_into_tensor, "
+              "broadcast of float / uint8 views): every collective is the identity, results must equal the single process",
               "config": "reference defaults: cone 0.004, alpha_thre 0.01 (sigma_fn pre-pass on), 4-level 128^3 grid",
               "single_process": {"samples_per_step": n_ref, "occupied_fraction_after_refresh": occ_ref,
                                  "run_to_run_first_grad_err": grad_err(g_ref2), "run_to_run_max_abs_param_diff": floor_p,

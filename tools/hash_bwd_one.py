@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One hash-backward configuration on one regime, a few launches (for rocprofv3 --pmc passes).
-usage: python tools/hash_bwd_one.py <M-march|M-packed|default> [opt=val ...]"""
+usage: python tools/hash_bwd_one.py <M-march|M-packed|bench|default> [opt=val ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +29,13 @@ if regime == "M-march":
 elif regime == "M-packed":
     o, d = bench.sphere_rays(R, torch.Generator().manual_seed(96))
     x01 = fixed(o, d)
+elif regime == "bench":                 # the positions of bench.py's headline step (SURVEY 8d rays, chord inside the box)
+    model, rb, _, jitter = bench.build_workload(dev, 96)
+    cfg = model.config
+    ri, ts, te, packed = model.occupancy_grid.sampling(
+        rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+        render_step_size=cfg.render_step_size, stratified=True, jitter=jitter, return_packed=True)[:4]
+    x01 = ops.positions(rb.origins.detach(), rb.directions.detach(), ri, ts, te, packed, True, None)[0]
 else:
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
     torch.manual_seed(96)
@@ -58,4 +65,26 @@ if nb:
 for _ in range(3):
     _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, ctypes.byref(o_), ops._stream())
 torch.cuda.synchronize()
-print(regime, n, "samples")
+# distinct 64-byte lines of the gradient table per 64-sample window (= one wave of the kernel), per level: the request floor
+lines = []
+for l in range(16):
+    sc = meta.scales[l]; res = meta.resolutions[l]; size = meta.offsets[l + 1] - meta.offsets[l]
+    p = x01 * sc + 0.5
+    p0 = p.floor().to(torch.int64)
+    tot = 0
+    acc = []
+    for c in range(8):
+        q = p0 + torch.tensor([c & 1, (c >> 1) & 1, (c >> 2) & 1], device=dev)
+        if res ** 3 <= size:
+            idx = q[:, 0] + q[:, 1] * res + q[:, 2] * res * res
+        else:
+            idx = (q[:, 0] ^ (q[:, 1] * 2654435761) ^ (q[:, 2] * 805459861)) & 0xFFFFFFFF
+        acc.append((idx % size) >> 3)
+    ln = torch.stack(acc, 1)                                     # [n, 8]
+    pad = (-n) % 64
+    if pad:
+        ln = torch.cat([ln, ln[-1:].expand(pad, 8)])
+    w = ln.reshape(-1, 64 * 8).sort(dim=1).values
+    lines.append(float(((w[:, 1:] != w[:, :-1]).sum() + w.shape[0]) / n))
+print(regime, n, "samples; distinct 64-B lines per sample in a 64-sample window, per level:", " ".join(f"{v:.2f}" for v in lines),
+      "sum", f"{sum(lines):.2f}")
