@@ -178,6 +178,30 @@ def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_fr
                     "backward -> Adam); occupancy refresh eager between replays"}
 
 
+def hash_bwd_request_floor(x01, meta):
+    """Distinct 64-byte lines of the gradient table that each 64-sample window (one wave of the hash backward) touches, summed over the
+    levels: the fewest float-atomic requests the kernel can send for these positions (a straight ray does not revisit fine cells, so a
+    longer window merges 1 - 2 % more).  tcnn's indexing: dense levels x + y*res + z*res^2, hashed levels
+    x ^ y*2654435761 ^ z*805459861 (mod level size); 8 entries of 2 floats per line."""
+    n = x01.shape[0]
+    total = 0
+    for l in range(len(meta.scales)):
+        res, size = meta.resolutions[l], meta.offsets[l + 1] - meta.offsets[l]
+        p0 = (x01 * meta.scales[l] + 0.5).floor().to(torch.int64)
+        cols = []
+        for c in range(8):
+            qx, qy, qz = p0[:, 0] + (c & 1), p0[:, 1] + ((c >> 1) & 1), p0[:, 2] + ((c >> 2) & 1)
+            idx = qx + qy * res + qz * res * res if res ** 3 <= size else (qx ^ (qy * 2654435761) ^ (qz * 805459861)) & 0xFFFFFFFF
+            cols.append((idx % size) >> 3)
+        ln = torch.stack(cols, 1)
+        if n % 64:
+            ln = torch.cat([ln, ln[-1:].expand(64 - n % 64, 8)])
+        w = ln.reshape(-1, 512).sort(dim=1).values
+        total += int((w[:, 1:] != w[:, :-1]).sum()) + w.shape[0]
+        del ln, w, cols, p0
+    return total
+
+
 def sphere_rays(R, gen):
     """SURVEY.md 8d ray distribution: origins uniform on the sphere of radius 1.5, aimed at uniform targets in [-0.5, 0.5]^3."""
     o = torch.randn(R, 3, generator=gen)
@@ -447,7 +471,7 @@ def main():
     ap.add_argument("--no-context", action="store_true", help="skip the default-config / M-packed context runs")
     args = ap.parse_args()
 
-    from lsenerf_amd import _lib, dist as ldist
+    from lsenerf_amd import _lib, ops, dist as ldist
     from lsenerf_amd.optim import FlatAdam, FlatParams
     import torch.distributed as tdist
 
@@ -539,6 +563,24 @@ def main():
             sq_busy = pmc.get("matrix_core_busy")
         except OSError:
             pass
+        atomic = None
+        if dom == "lse_hash_bwd":
+            # second roofline of the dominant kernel: it scatters with float atomics, which gfx950 executes at the memory side at a
+            # chip-wide REQUEST rate (MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of 64-byte requests = ~20 G requests/s;
+            # tools/micro/atomic_gran.hip: 21 G/s), far below the HBM byte rate the contract's `frac` is priced against
+            with torch.no_grad():
+                cfg_ = model.config
+                ri_, ts_, te_, pk_ = model.occupancy_grid.sampling(
+                    rb.origins.detach(), rb.directions.detach(), near_plane=cfg_.near_plane, far_plane=cfg_.far_plane,
+                    render_step_size=cfg_.render_step_size, stratified=True, jitter=jitter, return_packed=True)[:4]
+                x01_ = ops.positions(rb.origins.detach(), rb.directions.detach(), ri_, ts_, te_, pk_, True, None)[0]
+                req = hash_bwd_request_floor(x01_, model.field.mlp_base_grid.meta)
+                del ri_, ts_, te_, pk_, x01_
+            atomic = {"bound": "memory-side float atomics (requests of <= 64 B)", "request_floor_per_launch": req,
+                      "requests_per_sample": req / n_samples, "peak_requests_per_s": 21e9,
+                      "achieved_requests_per_s": req / (dom_ms * 1e-3), "frac": req / (dom_ms * 1e-3) / 21e9,
+                      "note": "floor = distinct 64-B table lines per 64-sample wave window, all 16 levels; the kernel sends 12 - 15 % "
+                              "more (cache collisions; profiles/r03_hash_bwd_memory_side_requests.txt)"}
         line = {
             "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -552,7 +594,8 @@ def main():
                        "parallelism": f"dp{world}", "grad_exchange": mode},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples},
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples,
+                         "atomic": atomic},
             "step_roofline": {"algorithmic_bytes_per_step": b_step,
                               "achieved_GBps": b_step / (ms_per_step * 1e-3) / 1e9 * 1.0,
                               "frac_of_hbm_peak": b_step / (ms_per_step * 1e-3) / HBM_PEAK},

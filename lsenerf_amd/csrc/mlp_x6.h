@@ -26,6 +26,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define LSE_MFMA_BF(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define LSE_MFMA_BF16K(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, (a)), __builtin_bit_cast(s16x4, (b)), (c), 0, 0, 0)
 
 // one float -> piece p (0 hi, 1 mid, 2 lo) as a bf16 bit pattern, by truncation: the remainders are exact in f32 and the third
 // piece is exactly representable (weight images, cut once per workgroup)
@@ -83,12 +87,17 @@ __device__ __forceinline__ void split_pair(f32x4 c0, f32x4 c1, const NI &nI, u32
 template <typename NI>
 __device__ __forceinline__ void split_half(f32x4 c0, const NI &nI, uint32_t (&hi)[2], uint32_t (&mid)[2], uint32_t (&lo)[2])
 {
+    // the remainder products have k = 16: the two-register v_mfma_f32_16x16x16_bf16 takes the same 16 cycles as the k = 32 form
+    // (tools/micro/mfma_rate.hip) and needs no zero upper half (two v_mov per product in the k = 32 form).  Its A operand is the
+    // first half of "minus identity" variant 0: lane (row i, group q) holds k = 4q .. 4q+3 -> -1 at k = i.
+    const u32x4 n4 = nI[0];
+    const u32x2 n2 = (u32x2){n4[0], n4[1]};
     hi[0] = cvt_pk(c0[0], c0[1]);
     hi[1] = cvt_pk(c0[2], c0[3]);
-    c0 = LSE_MFMA_BF(nI[0], ((u32x4){hi[0], hi[1], 0u, 0u}), c0);
+    c0 = LSE_MFMA_BF16K(n2, ((u32x2){hi[0], hi[1]}), c0);
     mid[0] = cvt_pk(c0[0], c0[1]);
     mid[1] = cvt_pk(c0[2], c0[3]);
-    c0 = LSE_MFMA_BF(nI[0], ((u32x4){mid[0], mid[1], 0u, 0u}), c0);
+    c0 = LSE_MFMA_BF16K(n2, ((u32x2){mid[0], mid[1]}), c0);
     lo[0] = cvt_pk(c0[0], c0[1]);
     lo[1] = cvt_pk(c0[2], c0[3]);
 }
@@ -459,7 +468,6 @@ __global__ __launch_bounds__(512) void mlp_fwd3_kernel(MlpArgs a, bool nt)
 // ------------------------------------------------------------------------------------------------------
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // byte offset of 8-byte chunk `chunk` of 32-byte segment `seg` of row `row` in an image with S segments (16 bf16) per row
 template <int S>
@@ -494,6 +502,13 @@ __device__ __forceinline__ void stage_plain(uint8_t *img, const float *W, int ld
         *reinterpret_cast<uint32_t *>(img + p * (ROWS * COLS * 2) + img_off<S>(row, c0 >> 4, (c0 & 15) >> 2) + 4 * (cp & 1)) =
             piece_of(v0, p) | (piece_of(v1, p) << 16);
     }
+}
+
+// gradient through a ReLU whose "was positive" bits are packed in m: bit `pos` set -> g, clear -> +0.  Two instructions
+// (v_bfe_i32 spreads the bit over the word, v_and) instead of the three of a test + select.
+__device__ __forceinline__ float relu_gate(float g, uint32_t m, int pos)
+{
+    return __uint_as_float(__float_as_uint(g) & (uint32_t)__builtin_amdgcn_sbfe((int)m, (unsigned)pos, 1u));
 }
 
 // six piece products into one accumulator: a[], b[] = {hi, mid, lo}
@@ -545,6 +560,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
     do {                                                   \
         if constexpr (NW > 4) __builtin_amdgcn_sched_barrier(0); \
     } while (0)
+// (tools/asm_mix.py: -DLSE_PHASE_MARKS leaves "; LSE_PHASE name" comments in the listing so that the instruction mix can be read per phase)
+#ifdef LSE_PHASE_MARKS
+#define LSE_PHASE(name) asm volatile("; LSE_PHASE " name)
+#else
+#define LSE_PHASE(name) do {} while (0)
+#endif
     constexpr int TS = 16 * CT, HB = 4, WIDTH = 64, S0 = C::S0, KB0 = KIN / 16;
     constexpr bool MS = (KIN == 32);      // remainder MFMAs on pairs of row blocks (base) / on single blocks (head: fewer live registers)
     static_assert((KIN == 16 && NHL == 2 && INL == LSE_IN_ROWMAJOR) || (KIN == 32 && NHL == 1), "head or base shape");
@@ -789,6 +810,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             sl[ct] = valid[ct] ? ct * 16 + j : n_rem - 1;
         }
         // ---- loads
+        LSE_PHASE("loads");
         f32x4 raw[CT][KIN / 16];
         load_in_x6<KIN, INL, CT>(a, tile, j, q, raw);
         // per-row bias: row of this lane's sample per column tile (accumulator layout), as a 32-bit offset from a wave-uniform base
@@ -848,6 +870,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         // ---- first hidden layer again, one row block at a time: relu(W0 in + bias) -> mask bits + pieces
+        LSE_PHASE("h0");
         PiecesB<HB> x[CT];
         uint32_t m0[CT] = {}, m1[CT] = {};      // ReLU masks, bit 4rb + r
         {
@@ -904,6 +927,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
         }
         if constexpr (NHL == 2) {
             // ---- second hidden layer again; its pieces go straight to the tile (they are only needed transposed, for dWo)
+            LSE_PHASE("h1");
             PiecesB<HB> x1[CT];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -945,6 +969,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             for (int rb = 0; rb < HB; ++rb) write_buf_rb(rb, x);
         }
         // ---- output gradient: pieces to the small tile (-> A operand of dWo), combos for dH_last;  dWo += G_out^T * H_last
+        LSE_PHASE("dWo");
         PiecesB16 gx[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -986,6 +1011,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         // ---- dH_last = Wo^T G_out (16 rows of Wo: k = 16), masked; pieces to the tile and into registers
+        LSE_PHASE("dHlast");
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             f32x4 dh[2][CT];
@@ -1002,7 +1028,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                     dh[b][ct] = LSE_MFMA_BF(wc[0], gx[ct].c[0], c);
                     const uint32_t m = (NHL == 2) ? m1[ct] : m0[ct];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dh[b][ct][r] = ((m >> (4 * rb + r)) & 1u) ? dh[b][ct][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) dh[b][ct][r] = relu_gate(dh[b][ct][r], m, 4 * rb + r);
                 }
                 split_block_single(s2, b, dh[b], x);
                 if constexpr (!MS) {
@@ -1019,6 +1045,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
         }
         if constexpr (NHL == 2) {
             lds_sync();
+            LSE_PHASE("dW1");
             // ---- dW1 += G1^T * H0, with H0^T computed directly in operand layout (rows = samples): in * W0^T + bias.
             // (the pieces of G1 in registers are dropped here and come back from the tile for dH0)
             {
@@ -1077,6 +1104,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
                 }
             }
             // ---- dH0 = W1^T G1, masked, one output block at a time; its pieces replace G1's in the tile
+            LSE_PHASE("dH0");
             read_buf_own(x);
             lds_sync();
 #pragma unroll
@@ -1097,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) d0[b][ct][r] = ((m0[ct] >> (4 * cb + r)) & 1u) ? d0[b][ct][r] : 0.f;
+                        for (int r = 0; r < 4; ++r) d0[b][ct][r] = relu_gate(d0[b][ct][r], m0[ct], 4 * cb + r);
                     if constexpr (!MS) {
                         PiecesB<HB> y1[CT];
                         split_block_single(s2, b, d0[b], y1);
@@ -1116,6 +1144,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             read_buf_own(x);         // dH0 pieces (B operand of dIn)
         }
         // ---- per-row bias gradient of a column tile that straddles two rows (rare): segmented scan on dH0 = hi + mid + lo
+        LSE_PHASE("bias");
         float ones[CT] = {};
         if (BIAS && a.d_row_bias) {
             bool col_taken = false;          // both column tiles feed ONE product: only one row per tile may use the column
@@ -1152,6 +1181,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         // layer-0 input as the B operand of dW0 (lane = input column, slots = samples)
+        LSE_PHASE("dW0");
         u32x4 ib[KB0][3];
         if constexpr (KIN == 16) {
             // through the small tile (the output gradient there has been consumed)
@@ -1206,6 +1236,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         // ---- dIn = W0^T dH0
+        LSE_PHASE("dIn");
         if (a.d_in) {
 #pragma unroll
             for (int cb = 0; cb < KB0; ++cb) {
@@ -1235,6 +1266,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
             }
         }
         lds_sync();
+        LSE_PHASE("end");
     }
     if (BIAS_ONES) flush_bias_col();
     flush_wgrad<HB, KB0>(a.d_params + a.w0_col, a.w0_ld, KIN, acc0, j, q, a.w0_mask0 != 0);
