@@ -149,12 +149,36 @@ def _timed_steps(step_fn, steps, warmup, breakdown_steps=8):
     return ms, kern, launches
 
 
-def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None):
+def _snapshot(model, opt):
+    """Parameters, optimizer state and occupancy grid: the two graphed variants are timed from the SAME training state (the
+    synthetic scene keeps training during a timing, which moves the grid and with it the sample count)."""
+    est = model.occupancy_grid
+    return (opt.flat.data.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, est.occs.clone(), est.binaries.clone())
+
+
+def _restore(model, opt, snap):
+    est = model.occupancy_grid
+    with torch.no_grad():
+        opt.flat.data.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
+        opt.step_count = snap[3]
+        est.occs.copy_(snap[4]); est.binaries.copy_(snap[5])
+    est._bump_grid_version()
+    est._occ_mean_host = None
+    if "_occ_mean_dev" in est.__dict__:
+        est.__dict__["_occ_mean_dev_version"] = None
+        est._occ_mean_device()
+
+
+def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None, prefetch=False):
     """The same step as ONE replayed HIP graph (lsenerf_amd.graph.GraphedTrainStep: device-side sample counts, staged Adam
     scalars, jitter drawn inside the graph; the occupancy refresh stays an eager in-place call between replays).
+    ``prefetch``: the graph also marches the NEXT step's rays on a side stream (here: the same rays, announced at every call; on the
+    refresh steps the samples marched ahead are stale and the rays are marched again, inside the timing).
     Returns {"ms_per_step", "host_ms_per_step"}."""
     from lsenerf_amd.graph import GraphedTrainStep
-    step = GraphedTrainStep(model, opt, col, prev, nxt, batch, ray_grads=True)
+    step = GraphedTrainStep(model, opt, col, prev, nxt, batch, ray_grads=True, prefetch_march=prefetch,
+                            prefetch_fork=os.environ.get("LSE_BENCH_PREFETCH_FORK", "hash_bwd"))
+    kw = {"next_bundles": (col, prev, nxt)} if prefetch else {}
     k = 0
 
     def run(n):
@@ -162,7 +186,7 @@ def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_fr
         for _ in range(n):
             if refresh_from is not None:
                 model.update_occupancy_grid(refresh_from + k)
-            step(col, prev, nxt, batch)
+            step(col, prev, nxt, batch, **kw)
             k += 1
     run(warmup)
     torch.cuda.synchronize()
@@ -175,7 +199,9 @@ def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_fr
     step.close()
     return {"ms_per_step": ms, "host_ms_per_step": host / steps * 1e3,
             "note": "one hipGraph replay per step (sampler with device-side counts -> field -> volume rendering -> loss epilogue -> "
-                    "backward -> Adam); occupancy refresh eager between replays"}
+                    "backward -> Adam); occupancy refresh eager between replays" +
+                    ("; the marcher of the NEXT step's rays runs on a side stream inside the same graph (two graphs alternate "
+                     "between two sample buffers)" if prefetch else "")}
 
 
 def hash_bwd_request_floor(x01, meta):
@@ -249,9 +275,14 @@ def context_default_config(device, steps=20, warmup=6):
 
     ms, kern, launches = _timed_steps(step, steps, warmup)
     kept = int(step.last["num_samples_per_ray"].sum())
+    snap = _snapshot(model, opt)
     graphed = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None}, steps, warmup,
-                              refresh_from=200)
+                              refresh_from=320)
     graphed["rays_per_s"] = R / (graphed["ms_per_step"] * 1e-3)
+    _restore(model, opt, snap)
+    graphed["marcher_prefetched"] = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
+                                                    steps, warmup, refresh_from=320, prefetch=True)
+    graphed["marcher_prefetched"]["rays_per_s"] = R / (graphed["marcher_prefetched"]["ms_per_step"] * 1e-3)
     # candidates before culling: one more marcher call (untimed)
     with torch.no_grad():
         cand = est.sampling(rb.origins.detach(), rb.directions.detach(), sigma_fn=None, near_plane=0.05, far_plane=1e3,
@@ -371,8 +402,14 @@ def context_composition(device, kind, steps=16, warmup=6):
     kern, launches = _event_pass(step, warmup + steps, 8, None)
     kept = sum(int(v["num_samples_per_ray"].sum()) for v in last["out"].values() if v is not None)
     rays = sum(sizes)
-    graphed = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=200)
+    snap = _snapshot(model, opt)
+    graphed = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=320)
     graphed["rays_per_s"] = rays / (graphed["ms_per_step"] * 1e-3)
+    if kind == "cfg2":      # (cfg 4's rays come from poses the step itself updates: nothing to march ahead)
+        _restore(model, opt, snap)
+        graphed["marcher_prefetched"] = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=320,
+                                                        prefetch=True)
+        graphed["marcher_prefetched"]["rays_per_s"] = rays / (graphed["marcher_prefetched"]["ms_per_step"] * 1e-3)
     return {"workload": {"cfg2": "colour + prev + next event bundle (2316 / 597 / 597 rays), co_map routing, rgb + event loss",
                          "cfg4": "BAD-NeRF deblur: 878 pixels x 4 virtual cameras = 3512 rays, rgb loss on the 4-ray mean, pose gradients"}[kind]
                         + "; ONE packed pass per step (train_step_bundles), reference default sampler configuration, carved grid, "
@@ -624,6 +661,10 @@ def main():
             line["m_march_graphed"] = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
                                                       min(args.steps, 20), 4)
             line["m_march_graphed"]["rays_per_s"] = RAYS_PER_GPU / (line["m_march_graphed"]["ms_per_step"] * 1e-3)
+            pf = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
+                                 min(args.steps, 20), 4, prefetch=True)
+            pf["rays_per_s"] = RAYS_PER_GPU / (pf["ms_per_step"] * 1e-3)
+            line["m_march_graphed"]["marcher_prefetched"] = pf
             del model, flat, opt
             torch.cuda.empty_cache()
             line["m_march_inside_box"] = context_inside_box(device)

@@ -298,6 +298,8 @@ def sync_grid(estimator, src: int = 0) -> None:
     dist.broadcast(estimator.occs, src=src)
     b8 = estimator.binaries.view(torch.uint8) if estimator.binaries.dtype == torch.bool else estimator.binaries
     dist.broadcast(b8, src=src)
+    if hasattr(estimator, "_bump_grid_version"):
+        estimator._bump_grid_version()
     if hasattr(estimator, "_occ_mean_host"):
         estimator._occ_mean_host = None
     if "_occ_mean_dev" in getattr(estimator, "__dict__", {}):      # device-side copy of occs.mean() (count-free sampler path)

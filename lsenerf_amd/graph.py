@@ -17,6 +17,17 @@ What varies from step to step enters through device memory at fixed addresses:
     ``LSENeRFModel.update_occupancy_grid`` between replays (lse_visibility_mask_cap reads the mean on the device).
 Everything else (step size, cone angle, shapes, capacities) is constant for a given model and batch composition.
 The values are those of the eager step: the same kernels run on the same samples (tests/test_gpu_graph.py).
+
+``prefetch_march``: the ray marcher reads the rays and the occupancy grid and nothing else -- no parameters -- and it is the one
+kernel of the step that cannot fill the chip (one wave per ray, a serial float recurrence: 0.26 - 0.31 ms for 3510 rays, 10 % of the
+3-bundle step).  With prefetching the step's graph forks: a side stream marches the NEXT step's rays while the main stream runs the
+current step on the samples the previous replay left behind; the side stream forks off right before the hash backward, whose
+launch waits for the memory-side atomic units rather than for the CUs (tools/overlap_probe.py: issued together on two streams the two
+kernels take 1.52 ms against 0.31 + 1.38 one after the other).  Inside the graph the gain is a quarter of the marcher: 2.67 -> 2.61 ms
+per step in the reference's default configuration, 2.70 -> 2.63 for the 3-bundle step, 5.82 -> 5.74 at the metric size.  Two graphs alternate between two sample buffers (one reads A and fills B, the other reads B and fills A), so
+nothing is copied.  The marcher of a step therefore sees the occupancy grid as it was one step earlier: when the grid has
+changed in between (``LSEOccGridEstimator.grid_version``; every 16th step), or no rays were announced, the current rays are
+marched again, eagerly, before the replay -- the samples are always those of the eager step.
 """
 from __future__ import annotations
 
@@ -58,7 +69,7 @@ def _copy_bundle(dst: Optional[RayBundle], src: Optional[RayBundle]) -> None:
             v.copy_(src.metadata[k], non_blocking=True)
 
 
-def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3):
+def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool=None):
     """Capture ``body()`` -- a zero-argument callable that runs one step on tensors at fixed addresses and synchronises with
     nothing -- into a HIP graph.  Warm-up runs on a side stream as torch.cuda.graph requires (allocator pools, lazy
     initialisation); the optimizer state those eager runs change is saved and restored, so capturing trains nothing.
@@ -78,7 +89,7 @@ def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3):
     graph = torch.cuda.CUDAGraph()
     if opt is not None:
         opt.prepare_step()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, pool=pool):
         body()
     # the capture records launches, it does not run them: the overflow flag of a captured marcher call means something only
     # after a replay -- it is handed to the caller instead of staying in the estimator's list
@@ -104,11 +115,13 @@ class GraphedTrainStep:
     ``ray_grads=True`` makes the static ray tensors leaves that require gradients (BASELINE config 4: BAD-NeRF pose
     optimisation); their ``.grad`` after a replay is the gradient of the summed loss w.r.t. the rays that were copied in.
     ``jitter``: "graph" draws the stratified offsets inside the graph; a tensor-valued call argument ``jitter=`` is copied
-    into a static input instead when the object was built with ``jitter="input"``."""
+    into a static input instead when the object was built with ``jitter="input"``.
+    ``prefetch_march=True`` (module docstring): announce the next step's rays with ``next_bundles=(col, prev, nxt)`` (and
+    ``next_jitter=`` for jitter="input") at every call; the next call must then be given exactly those rays."""
 
     def __init__(self, model, opt: FlatAdam, col: Optional[RayBundle], prev: Optional[RayBundle], nxt: Optional[RayBundle],
                  batch: Dict[str, object], ray_grads: bool = False, jitter: str = "graph", warmup: int = 3,
-                 grad_scale: float = 1.0):
+                 grad_scale: float = 1.0, prefetch_march: bool = False, prefetch_fork: str = "hash_bwd"):
         assert jitter in ("graph", "input")
         assert model.training, "the captured step is the training step"
         self.model, self.opt, self.grad_scale = model, opt, grad_scale
@@ -121,8 +134,34 @@ class GraphedTrainStep:
         self.jitter = torch.rand(n_total, device=dev) if jitter == "input" else None
         self.losses: Dict[str, Tensor] = {}
         self.outputs = None
-        self.graph, self._overflow_flags = capture_body(self._body, opt, model.occupancy_grid, warmup)
+        self.prefetch = bool(prefetch_march)
+        assert prefetch_fork in ("start", "hash_bwd")
+        self.prefetch_fork = prefetch_fork
         self.replays = 0
+        if not self.prefetch:
+            self.graph, self._overflow_flags = capture_body(self._body, opt, model.occupancy_grid, warmup)
+            return
+        # -- marcher of the next step on a side stream: two graphs alternate between two sample buffers
+        self.next_col, self.next_prev, self.next_nxt = (_static_like(b, False) for b in (col, prev, nxt))
+        self.next_jitter = torch.rand(n_total, device=dev) if jitter == "input" else None
+        with torch.no_grad():
+            self._pm = [model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter) for _ in range(2)]
+        est = model.occupancy_grid
+        del est.__dict__.get("_deferred_flags", [])[-2:]          # these two buffers' flags are checked by check_overflow()
+        self._side = torch.cuda.Stream(device=dev)
+        self._graphs, self._losses_of, self._outputs_of, self._ray_grads_of = [], [], [], []
+        self._overflow_flags = [pm.overflow for pm in self._pm]
+        for x in (0, 1):
+            g, flags = capture_body(lambda x=x: self._body_prefetch(x), opt, est, warmup if x == 0 else 1,
+                                    pool=self._graphs[0].pool() if self._graphs else None)
+            self._graphs.append(g)
+            self._overflow_flags += flags
+            self._losses_of.append(self.losses)
+            self._outputs_of.append(self.outputs)
+            self._ray_grads_of.append(self._collect_ray_grads())
+        self._cur = 0                # the buffer that holds (or will be given) the samples of the rays in the static CURRENT bundles
+        self._pm_version = None      # grid_version under which the other buffer was filled by the last replay; None: not filled
+        self._last = 0
 
     @staticmethod
     def _static_batch(batch):
@@ -134,24 +173,67 @@ class GraphedTrainStep:
                 out[k] = v.detach().clone() if torch.is_tensor(v) else v
         return out
 
-    def _body(self):
+    def _body(self, premarched=None):
         self.opt.zero_grad()
         for b in (self.col, self.prev, self.nxt):
             if b is not None and b.origins.requires_grad:
                 b.origins.grad = None
                 b.directions.grad = None
-        out, losses, _ = self.model.train_step_bundles(self.col, self.prev, self.nxt, self.batch, jitter=self.jitter)
+        out, losses, _ = self.model.train_step_bundles(self.col, self.prev, self.nxt, self.batch, jitter=self.jitter,
+                                                       premarched=premarched)
         sum(losses.values()).backward()
         self.opt.step_staged(self.grad_scale)
         self.losses, self.outputs = losses, out
 
-    @property
-    def ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
+    def _body_prefetch(self, x: int):
+        """The step on the samples in buffer x; beside it, on the side stream, the marcher of the NEXT rays into buffer 1 - x.
+        Where the side stream forks off decides what the marcher shares the chip with: "start" = the whole step; "hash_bwd" = it
+        becomes runnable together with the hash backward (the last and longest kernel of the step, bound by the memory-side atomic
+        units rather than by the CUs).  Measured (tools/ab_prefetch_fork.sh, graphed step without -> with the marcher on the side
+        stream): "start" 2.668 -> 2.646 ms (default configuration) / 2.688 -> 2.662 (3-bundle step); "hash_bwd" 2.671 -> 2.605 /
+        2.699 -> 2.630; behind the fine levels of a two-launch hash backward: no gain (the split itself costs what the overlap
+        wins)."""
+        from . import ops
+        main = torch.cuda.current_stream()
+
+        forked = []
+
+        def fork():
+            if forked:                                 # (a step with several hash backwards: the first one forks)
+                return
+            forked.append(True)
+            cur = torch.cuda.current_stream()          # (the backward's stream when called from the autograd thread)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side), torch.no_grad():
+                self.model.premarch_bundles(self.next_col, self.next_prev, self.next_nxt, jitter=self.next_jitter, out=self._pm[1 - x])
+
+        saved = ops.BEFORE_HASH_BWD
+        try:
+            if self.prefetch_fork == "start":
+                fork()
+            else:
+                ops.BEFORE_HASH_BWD = fork
+            self._body(premarched=self._pm[x])
+        finally:
+            ops.BEFORE_HASH_BWD = saved
+        if not forked:          # (no hash backward ran: a frozen table)
+            fork()
+        main.wait_stream(self._side)
+
+    def _collect_ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
         return {k: (None if b is None or not b.origins.requires_grad else (b.origins.grad, b.directions.grad))
                 for k, b in (("col", self.col), ("prev", self.prev), ("next", self.nxt))}
 
+    @property
+    def ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
+        """Gradients w.r.t. the rays of the last replayed step (each of the two alternating graphs owns its gradient tensors)."""
+        return self._ray_grads_of[self._last] if self.prefetch else self._collect_ray_grads()
+
     def __call__(self, col: Optional[RayBundle], prev: Optional[RayBundle], nxt: Optional[RayBundle], batch: Dict[str, object],
-                 jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                 jitter: Optional[Tensor] = None, next_bundles: Optional[Sequence[Optional[RayBundle]]] = None,
+                 next_jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        if (next_bundles is not None or next_jitter is not None) and not self.prefetch:
+            raise ValueError("next_bundles / next_jitter belong to a step built with prefetch_march=True")
         _copy_bundle(self.col, col)
         _copy_bundle(self.prev, prev)
         _copy_bundle(self.nxt, nxt)
@@ -170,9 +252,37 @@ class GraphedTrainStep:
                     self.jitter.copy_(jitter, non_blocking=True)
             elif jitter is not None:
                 raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
+        if self.prefetch:
+            return self._replay_prefetch(next_bundles, next_jitter)
         self.opt.prepare_step()
         self.graph.replay()
         self.replays += 1
+        return self.losses
+
+    def _replay_prefetch(self, next_bundles, next_jitter) -> Dict[str, Tensor]:
+        est, x = self.model.occupancy_grid, self._cur
+        if self._pm_version is None or self._pm_version != est.grid_version:
+            # nothing was marched ahead for these rays, or the grid has been refreshed since: march them now (eagerly, same stream)
+            with torch.no_grad():
+                self.model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter, out=self._pm[x])
+        if next_bundles is not None:
+            for dst, src in zip((self.next_col, self.next_prev, self.next_nxt), next_bundles):
+                _copy_bundle(dst, src)
+            if self.next_jitter is not None:
+                with torch.no_grad():
+                    if next_jitter is None:
+                        self.next_jitter.uniform_()
+                    else:
+                        self.next_jitter.copy_(next_jitter, non_blocking=True)
+            elif next_jitter is not None:
+                raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
+        version = est.grid_version                 # (the grid cannot change while the replay runs: refreshes are eager, in order)
+        self.opt.prepare_step()
+        self._graphs[x].replay()
+        self.replays += 1
+        self._pm_version = version if next_bundles is not None else None
+        self._last, self._cur = x, 1 - x
+        self.losses, self.outputs = self._losses_of[x], self._outputs_of[x]
         return self.losses
 
     def check_overflow(self) -> None:

@@ -15,7 +15,7 @@ Differences from the reference, by design:
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple, Union
+from typing import Callable, List, NamedTuple, Optional, Tuple, Union
 
 import torch
 from torch import Tensor, nn
@@ -27,6 +27,18 @@ def _enlarge_aabb(aabb: Tensor, factor: float) -> Tensor:
     center = (aabb[:3] + aabb[3:]) / 2
     extent = (aabb[3:] - aabb[:3]) / 2
     return torch.cat([center - extent * factor, center + extent * factor])
+
+
+class Premarched(NamedTuple):
+    """Result of ``LSEOccGridEstimator.march_deferred``: packed samples of capacity extent with their count on the device."""
+    ray_indices: Tensor       # int32 [R * cap]
+    t_starts: Tensor          # [R * cap]
+    t_ends: Tensor            # [R * cap]
+    packed_info: Tensor       # int64 [R, 2]
+    n_dev: Tensor             # int64 [1]: valid leading entries
+    overflow: Tensor          # int32 [1]: != 0 if a ray exceeded the proven capacity (never expected; checked lazily)
+    grid_version: int         # LSEOccGridEstimator.grid_version when the marcher was launched
+    n_rays: int
 
 
 class LSEOccGridEstimator(nn.Module):
@@ -115,7 +127,7 @@ class LSEOccGridEstimator(nn.Module):
                  t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
                  cone_angle: float = 0.0, jitter: Optional[Tensor] = None, return_packed: bool = False,
-                 deferred: bool = False):
+                 deferred: bool = False, premarched: Optional["Premarched"] = None):
         """Sampling with spatial skipping (not differentiable).  Returns (ray_indices, t_starts, t_ends); with
         ``return_packed`` also ``packed_info`` and ray_indices stays int32.
 
@@ -123,10 +135,14 @@ class LSEOccGridEstimator(nn.Module):
         default path of this class once per stage).  Returns (ray_indices, t_starts, t_ends, packed_info, n_dev): the packed
         arrays have CAPACITY extent ``R * _cap_per_ray(...)``, ``n_dev`` (int64 [1], on the device) holds the number of valid
         leading entries, and every per-sample kernel downstream is handed ``n_dev`` (ops._call_n).  Values are those of the
-        default path bit for bit; only the extents of the arrays differ."""
+        default path bit for bit; only the extents of the arrays differ.
+        ``premarched`` (deferred only): the result of ``march_deferred`` for these rays and marching parameters -- the marcher
+        is then not run again (it depends on the rays and the grid only, so it may run ahead of its step)."""
+        if premarched is not None and not deferred:
+            raise ValueError("premarched samples belong to the deferred (count-free) path")
         if deferred:
             return self._sampling_deferred(rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max,
-                                           render_step_size, early_stop_eps, alpha_thre, stratified, cone_angle, jitter)
+                                           render_step_size, early_stop_eps, alpha_thre, stratified, cone_angle, jitter, premarched)
         # near / far planes clamped by t_min / t_max, stratified start offset u * step (one launch, bit-identical to the
         # reference's full_like / clamp / rand_like-multiply-add sequence)
         u = None
@@ -168,21 +184,49 @@ class LSEOccGridEstimator(nn.Module):
             return ray_indices, t_starts, t_ends, packed_info
         return ray_indices.long(), t_starts, t_ends
 
-    def _sampling_deferred(self, rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
-                           early_stop_eps, alpha_thre, stratified, cone_angle, jitter):
+    @property
+    def grid_version(self) -> int:
+        """Counts the changes of ``binaries`` made through this class (refreshes, mark_all_occupied, dist.sync_grid): samples
+        marched ahead of their step are valid while it has not moved."""
+        return self.__dict__.get("_grid_version", 0)
+
+    def _bump_grid_version(self) -> None:
+        self.__dict__["_grid_version"] = self.grid_version + 1
+
+    @torch.no_grad()
+    def march_deferred(self, rays_o: Tensor, rays_d: Tensor, near_plane: float = 0.0, far_plane: float = 1e10,
+                       t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                       stratified: bool = False, cone_angle: float = 0.0, jitter: Optional[Tensor] = None,
+                       out: Optional["Premarched"] = None) -> "Premarched":
+        """The marcher half of ``sampling(deferred=True)``: near / far planes, ray marching through the occupancy grid, packing.
+        It reads the rays and the grid and nothing else -- no parameters -- so it can run ahead of the step that consumes its
+        samples (on a side stream, behind the previous step's backward pass; lsenerf_amd.graph.GraphedTrainStep).  ``out``: a
+        previous result for the same number of rays and the same marching parameters, overwritten in place."""
         u = None
         if stratified:
             u = jitter if jitter is not None else torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device)
         near_planes, far_planes = ops.ray_planes(rays_o.shape[0], rays_o.device, near_plane, far_plane, t_min, t_max, u,
                                                  render_step_size)
         cap = self._cap_per_ray(near_plane, far_plane, render_step_size, cone_angle)
-        ray_indices, t_starts, t_ends, packed_info, n_dev, overflow = ops.traverse_grids_deferred(
+        res = ops.traverse_grids_deferred(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
-            render_step_size, cone_angle, cap)
-        flags = self.__dict__.setdefault("_deferred_flags", [])
-        flags.append(overflow)
-        if len(flags) > 4096:
-            del flags[:2048]
+            render_step_size, cone_angle, cap, out=None if out is None else tuple(out)[:6])
+        if out is None:       # (the owner of reused buffers checks their flag itself: Premarched.overflow)
+            flags = self.__dict__.setdefault("_deferred_flags", [])
+            flags.append(res[5])
+            if len(flags) > 4096:
+                del flags[:2048]
+        return Premarched(*res, self.grid_version, rays_o.shape[0])
+
+    def _sampling_deferred(self, rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
+                           early_stop_eps, alpha_thre, stratified, cone_angle, jitter, premarched=None):
+        if premarched is None:
+            premarched = self.march_deferred(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size, stratified,
+                                             cone_angle, jitter)
+        elif premarched.n_rays != rays_o.shape[0]:
+            raise ValueError(f"premarched samples are for {premarched.n_rays} rays, {rays_o.shape[0]} given")
+        # (a stale grid_version is the caller's to check before the launch: a captured step cannot)
+        ray_indices, t_starts, t_ends, packed_info, n_dev = tuple(premarched)[:5]
         if self.after_march_hook is not None:
             self.after_march_hook()
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
@@ -277,6 +321,7 @@ class LSEOccGridEstimator(nn.Module):
             ops.occ_update_cells(self.occs, cell_ids, occ.contiguous().float(), ema_decay)
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre).reshape(1).contiguous()
         ops.occ_binarize(self.occs, thre, self._binaries_u8().view(-1))
+        self._bump_grid_version()
         self._occ_mean_host = None
         # the HIP kernels write `occs` through its raw pointer (no tensor version bump): refresh the device-side mean explicitly,
         # now and in place -- a captured step reads that buffer at its fixed address
@@ -291,4 +336,5 @@ class LSEOccGridEstimator(nn.Module):
         """Benchmark helper: the 'grid fully occupied' regime of training steps < 256."""
         self.occs.fill_(value)
         self.binaries.fill_(True)
+        self._bump_grid_version()
         self._occ_mean_host = None

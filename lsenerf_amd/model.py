@@ -263,8 +263,19 @@ class VolumetricSampler(nn.Module):
             return density_fn(positions, times[ri]).squeeze(-1)
         return sigma_fn
 
+    def premarch(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
+                 cone_angle: float = 0.0, jitter: Optional[Tensor] = None, out=None):
+        """The marcher of ``sample_packed`` alone (LSEOccGridEstimator.march_deferred): it needs the rays and the grid only, so it
+        may be launched ahead of the step that consumes the samples; hand the result to ``sample_packed(premarched=...)``."""
+        t_min = ray_bundle.nears.contiguous().reshape(-1) if ray_bundle.nears is not None else None
+        t_max = ray_bundle.fars.contiguous().reshape(-1) if ray_bundle.fars is not None else None
+        return self.occupancy_grid.march_deferred(
+            ray_bundle.origins.detach().contiguous(), ray_bundle.directions.detach().contiguous(), near_plane=near_plane,
+            far_plane=1e10 if far_plane is None else far_plane, t_min=t_min, t_max=t_max, render_step_size=render_step_size,
+            stratified=self.training, cone_angle=cone_angle, jitter=jitter, out=out)
+
     def sample_packed(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,
-                      alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None):
+                      alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None, premarched=None):
         """The sampler call of ``forward`` for the packed fast path, WITHOUT reading a sample count back to the host and without
         building per-sample ``RaySamples`` (gathered origins / directions / camera indices): returns (ray_indices int32,
         t_starts, t_ends, packed_info, n_dev) with capacity-extent arrays (LSEOccGridEstimator.sampling(deferred=True))."""
@@ -276,7 +287,8 @@ class VolumetricSampler(nn.Module):
             rays_o=rays_o.detach(), rays_d=rays_d.detach(), t_min=t_min, t_max=t_max,
             sigma_fn=self.get_sigma_fn(rays_o.detach(), rays_d.detach(), ray_bundle.times),
             render_step_size=render_step_size, near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane,
-            stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, deferred=True)
+            stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, deferred=True,
+            premarched=premarched)
         ops.fake_sample_if_empty(packed, n_dev, ri, ts, te)     # "create a single fake sample" of forward(), on the device
         return ri, ts, te, packed, n_dev
 
@@ -451,7 +463,7 @@ class LSENeRFModel(nn.Module):
             ray_bundle = self.collider(ray_bundle)
         return self.get_outputs(ray_bundle, **kwargs)
 
-    def exec_get_outputs(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None):
+    def exec_get_outputs(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None, premarched=None):
         assert self.field is not None
         num_rays = len(ray_bundle)
         cfg = self.config
@@ -459,8 +471,10 @@ class LSENeRFModel(nn.Module):
             # no sample count visits the host: capacity-extent arrays + a device-side count handed to every per-sample kernel
             ri, ts, te, packed, n_dev = self.sampler.sample_packed(
                 ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
-                alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter)
+                alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter, premarched=premarched)
             return self.render_packed(ray_bundle, ri, ts, te, packed, n_dev=n_dev)
+        if premarched is not None:
+            raise ValueError("premarched samples need the count-free packed path (training, LSEField, use_deferred_counts)")
         ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=cfg.near_plane,
                                                 far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
                                                 alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle, jitter=jitter)
@@ -584,7 +598,7 @@ class LSENeRFModel(nn.Module):
     # -- the reference's training step (R:lse_nerf/lse_pipeline.py:110-145) as ONE packed pass ----------------------------
     def train_step_bundles(self, col_bundle: Optional[RayBundle], prev_bundle: Optional[RayBundle],
                            next_bundle: Optional[RayBundle], batch: Dict[str, object], jitter: Optional[Tensor] = None,
-                           with_metrics: bool = False):
+                           with_metrics: bool = False, premarched=None):
         """``LSENeRFPipeline.get_train_loss_dict`` for bundles the data manager has already produced: returns
         ``(out_dict, loss_dict, metrics_dict)`` with ``out_dict = {"col_out", "prev_out", "next_out"}``.
 
@@ -595,7 +609,8 @@ class LSENeRFModel(nn.Module):
         volume-rendering kernel, one loss epilogue, ONE hash backward; per-bundle outputs are row slices of the packed
         result.  Every ray gets exactly the samples and values it gets in a pass of its own (``jitter``: one stratified
         offset per ray, colour rays first, for callers that need the draw reproduced); only the order in which gradient
-        contributions are summed differs.  ``with_metrics``: also route the colour render and report NGPModel's psnr /
+        contributions are summed differs.  ``premarched``: the result of ``premarch_bundles`` for these bundles (the ray marcher
+        run ahead of the step; ``jitter`` was applied there).  ``with_metrics``: also route the colour render and report NGPModel's psnr /
         num_samples_per_batch (R:lse_nerf/lsenerf.py:378-388) -- a handful of O(R) torch ops outside the fused epilogue."""
         assert self.training, "train_step_bundles is the training step; use forward() / get_outputs() for evaluation"
         names = ("col_out", "prev_out", "next_out")
@@ -606,7 +621,7 @@ class LSENeRFModel(nn.Module):
         rb = RayBundle.cat([b for _, b in given])
         if self.collider is not None:
             rb = self.collider(rb)
-        raw = self.exec_get_outputs(rb, jitter=jitter)
+        raw = self.exec_get_outputs(rb, jitter=jitter, premarched=premarched)
         out_dict: Dict[str, Optional[Dict[str, Tensor]]] = {k: None for k in names}
         lo = 0
         for k, b in given:
@@ -622,6 +637,19 @@ class LSENeRFModel(nn.Module):
                                            batch)
             metrics_dict = {f"{k1}_{k2}": v for k1, d in md.items() for k2, v in d.items()}   # flatten_metrics_dict (:100-107)
         return out_dict, loss_dict, metrics_dict
+
+    def premarch_bundles(self, col_bundle: Optional[RayBundle], prev_bundle: Optional[RayBundle],
+                         next_bundle: Optional[RayBundle], jitter: Optional[Tensor] = None, out=None):
+        """The ray marcher of ``train_step_bundles`` for these bundles, launched now (on torch's current stream): it reads the rays
+        and the occupancy grid only, so the NEXT step's marcher can run behind the current step's backward pass.  The result is
+        valid while ``occupancy_grid.grid_version`` equals its ``grid_version``."""
+        cfg = self.config
+        given = [b for b in (col_bundle, prev_bundle, next_bundle) if b is not None and len(b) > 0]
+        rb = RayBundle.cat(given)
+        if self.collider is not None:
+            rb = self.collider(rb)
+        return self.sampler.premarch(rb, near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,
+                                     cone_angle=cfg.cone_angle, jitter=jitter, out=out)
 
     # -- fused training epilogue -----------------------------------------------------------------------------
     def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor]]]:

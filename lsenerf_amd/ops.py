@@ -202,12 +202,14 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
 
 @torch.no_grad()
 def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
-                            cap: int):
+                            cap: int, out=None):
     """``traverse_grids`` without the host read-back of the sample count.  ``cap`` is a PROVEN upper bound of the samples of
     one ray (LSEOccGridEstimator._cap_per_ray); the packed outputs have room for ``R * cap`` samples and the actual count stays
     on the device.  Returns (ray_indices int32 [C], t_starts [C], t_ends [C], packed_info int64 [R,2], n_dev int64 [1],
     overflow int32 [1]) with C = R * cap; entries at and beyond n_dev[0] are never written nor read by the kernels that are
-    handed ``n_dev``.  ``overflow`` != 0 would mean the bound was violated (checked lazily by the caller, never expected)."""
+    handed ``n_dev``.  ``overflow`` != 0 would mean the bound was violated (checked lazily by the caller, never expected).
+    ``out``: a previous result of this function for the same R and cap, written into instead of allocating (a marcher that runs
+    ahead of its step on a side stream fills buffers at addresses the consumer already knows: lsenerf_amd.graph)."""
     R = rays_o.shape[0]
     L, rx, ry, rz = binaries.shape
     dev = rays_o.device
@@ -215,8 +217,15 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
     if not (0 < cap and C <= MAX_SLOT_ELEMS):
         raise _lib.LseHipError(f"deferred sampling: {R} rays x {cap} slots exceed the slot budget ({MAX_SLOT_ELEMS})")
     cnts = torch.empty(R, dtype=torch.int64, device=dev)
-    packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
-    total = torch.zeros(2, dtype=torch.int64, device=dev)
+    if out is not None:
+        ri, ts, te, packed, n_dev_o, flag_o = out
+        if not (ri.shape == ts.shape == te.shape == (C,) and packed.shape == (R, 2) and n_dev_o.data_ptr() + 8 == flag_o.data_ptr()):
+            raise _lib.LseHipError("traverse_grids_deferred: `out` is not a result of this function for the same rays x capacity")
+        total = torch.as_strided(n_dev_o, (2,), (1,))      # [count, overflow flag]: the pair the first call allocated
+        total.zero_()
+    else:
+        packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+        total = torch.zeros(2, dtype=torch.int64, device=dev)
     ts_slots = torch.empty(C, dtype=torch.float32, device=dev)
     te_slots = torch.empty(C, dtype=torch.float32, device=dev)
     flag = total[1:].view(torch.int32)
@@ -226,9 +235,10 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
               ctypes.c_void_p(te_slots.data_ptr()), ctypes.c_void_p(flag.data_ptr()), _stream())
     _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
-    ri = torch.empty(C, dtype=torch.int32, device=dev)
-    ts = torch.empty(C, dtype=torch.float32, device=dev)
-    te = torch.empty(C, dtype=torch.float32, device=dev)
+    if out is None:
+        ri = torch.empty(C, dtype=torch.int32, device=dev)
+        ts = torch.empty(C, dtype=torch.float32, device=dev)
+        te = torch.empty(C, dtype=torch.float32, device=dev)
     _lib.call("lse_compact_ray_slots", ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()), cap,
               ctypes.c_void_p(packed.data_ptr()), R, ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()),
               ctypes.c_void_p(te.data_ptr()), _stream())
@@ -455,6 +465,8 @@ class _HashFn(torch.autograd.Function):
         desc = meta.desc()
         opts = hash_bwd_opts_with_workspace(desc, x01.device)     # defaults + the coarse-level replica workspace
         split = HASH_BWD_SPLIT
+        if BEFORE_HASH_BWD is not None:        # e.g. fork a side stream here: the scatter below is the last big kernel of the backward pass
+            BEFORE_HASH_BWD()
         if split is not None and direct is not None and 0 < split[0] < meta.n_levels:
             # fine levels first (most of the table bytes); their gradients are final when the callback runs, so the caller
             # can start exchanging them while the coarse levels are still being computed (dist.OverlappedGradExchange)
@@ -587,6 +599,7 @@ class _MlpFn(torch.autograd.Function):
         return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None, None
 
 
+BEFORE_HASH_BWD = None       # callable run (in the autograd thread, on the backward's stream) right before the hash backward is launched
 HASH_BWD_SPLIT = None        # (level, callback) installed by dist.OverlappedGradExchange: two launches, callback in between
 DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated leaf .grad (see _direct_grad)
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass

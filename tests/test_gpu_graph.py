@@ -167,3 +167,41 @@ def test_graphed_step_feeds_a_pose_optimiser_outside_the_graph():
     assert nmax_err(t1, t0, 1e-12) < 3e-5
     for a, b in zip(p1, p0):
         assert nmax_err(a, b, 1e-12) < 1e-4
+
+
+def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_eager_step():
+    """prefetch_march=True: each replay marches the NEXT step's rays on a side stream (two graphs alternating between two sample
+    buffers).  The samples must be those the eager step draws: checked step by step through the losses, across an occupancy
+    refresh (the samples marched ahead are stale then and the rays are marched again) and across a call that announces no rays."""
+    from lsenerf_amd import ops
+    from lsenerf_amd.graph import GraphedTrainStep
+    (m_e, m_g), (o_e, o_g), batch_of = _setup(False)
+    steps = [batch_of(60 + 10 * it) for it in range(7)]
+    b0, batch0, jit0 = steps[0]
+    step = GraphedTrainStep(m_g, o_g, *b0, batch0, jitter="input", prefetch_march=True)
+    assert o_g.step_count == 0 and torch.equal(o_g.flat.data, o_e.flat.data)
+    ops.SYNC_STATS.update(seconds=0.0, count=0)
+    marched_again = []
+    for it in range(6):
+        if it == 3:                      # refresh between replays: grid_version moves, the samples marched during replay 2 are stale
+            for m in (m_e, m_g):
+                m.update_occupancy_grid(0)
+        bundles, batch, jit = steps[it]
+        nb, _, njit = steps[it + 1]
+        announce = it != 4               # step 4 announces nothing: step 5 has to march its own rays
+        before = (step._pm_version, m_g.occupancy_grid.grid_version)
+        marched_again.append(before[0] is None or before[0] != before[1])
+        sync_before = ops.SYNC_STATS["count"]
+        l_g = step(*bundles, batch, jitter=jit, next_bundles=nb if announce else None, next_jitter=njit if announce else None)
+        assert ops.SYNC_STATS["count"] == sync_before
+        l_g = {k: float(v) for k, v in l_g.items()}
+        l_e, _, _ = _eager_step(m_e, o_e, bundles, batch, jit, False)
+        for k in l_e:
+            assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (it, k, l_g[k], l_e[k])
+        assert o_g.step_count == o_e.step_count == it + 1
+        if it == 3:      # after four Adam steps: the bound of test_graphed_step_equals_eager_step (noise-dominated elements only)
+            d = (o_g.flat.data - o_e.flat.data).abs()
+            assert float((d > 1e-5 * float(o_e.flat.data.abs().max())).float().mean()) < 0.02
+    assert marched_again == [True, False, False, True, False, True]        # first call, refresh, nothing announced
+    step.check_overflow()
+    step.close()
