@@ -32,4 +32,11 @@ hf = out['hash_fwd_kernel']
 j = {"_comment": f"HBM-side traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only), run {pre} (profiles/{pre}_pmc_*.csv). Counter values are KiB: bytes = (FETCH_SIZE + WRITE_SIZE) * 1024. gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads exactly 1/2 for wide (16 B/lane) streaming reads and is UNCALIBRATED for the 4-8 B gathers these kernels issue, so the fetch side is a lower bound; WRITE_SIZE is exact for float atomics and 16-B stores.",
      "lse_hash_fwd": {"fetch_kib": round(hf['FETCH_SIZE']), "write_kib": round(hf['WRITE_SIZE']), "bytes": round((hf['FETCH_SIZE'] + hf['WRITE_SIZE']) * 1024)},
      "lse_hash_bwd": {"kernel": "hash_bwd_batched_kernel<true,512,2>", "fetch_kib": round(hb['FETCH_SIZE']), "write_kib": round(hb['WRITE_SIZE']), "bytes": round((hb['FETCH_SIZE'] + hb['WRITE_SIZE']) * 1024)}}
+try:      # keys other tools maintain in the same file (matrix_core_busy: tools/pmc_mlp.sh) survive a refresh of the traffic numbers
+    old = json.load(open('profiles/pmc_traffic.json'))
+    for k, v in old.items():
+        if k not in j:
+            j[k] = v
+except OSError:
+    pass
 json.dump(j, open('profiles/pmc_traffic.json', 'w'), indent=1)
