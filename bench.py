@@ -213,7 +213,7 @@ def hash_bwd_request_floor(x01, meta):
     total = 0
     for l in range(len(meta.scales)):
         res, size = meta.resolutions[l], meta.offsets[l + 1] - meta.offsets[l]
-        p0 = (x01 * meta.scales[l] + 0.5).floor().to(torch.int64)
+        p0 = (x01.double() * meta.scales[l] + 0.5).float().floor().to(torch.int64)      # fmaf(scale, x, 0.5): one rounding, as the kernels
         cols = []
         for c in range(8):
             qx, qy, qz = p0[:, 0] + (c & 1), p0[:, 1] + ((c >> 1) & 1), p0[:, 2] + ((c >> 2) & 1)

@@ -253,3 +253,25 @@ def test_outer_boundary_with_the_references_keyword_set():
     # the plugin entry point still fails with the explanatory message where nerfstudio is absent
     with pytest.raises(ModuleNotFoundError, match="nerfstudio==0.3.2"):
         ns_plugin.build_method_specification()
+
+
+def test_bench_request_floor_counts_the_lines_the_oracle_indexing_touches():
+    """bench.py's second roofline of the hash backward (roofline.atomic) rests on hash_bwd_request_floor: distinct 64-byte lines
+    of the gradient table per 64-sample window.  Checked here against a brute-force count over the oracle's corner indices."""
+    import numpy as np
+    import torch
+    import bench
+    from lsenerf_amd import ops
+    from oracle import hashgrid as oh
+    g = torch.Generator().manual_seed(5)
+    n = 64 * 7 + 13                                              # a ragged tail: the last window is padded with its last sample
+    t = torch.linspace(0.0, 1.0, n)[:, None]
+    x01 = (0.3 + 0.4 * t * torch.tensor([[0.6, -0.3, 0.74]]) + 0.2 * torch.rand(1, 3, generator=g)).clamp(0.0, 1.0)   # a straight ray
+    meta, ometa = ops.make_grid_meta(), oh.tcnn_grid_meta()
+    want = 0
+    for l in range(ometa.n_levels):
+        assert ometa.offsets[l] % 8 == 0                         # levels start on 64-byte lines
+        lines = (oh.tcnn_corner_indices(x01, ometa, l).numpy() - ometa.offsets[l]) >> 3
+        for s in range(0, n, 64):
+            want += np.unique(lines[s:s + 64]).size
+    assert bench.hash_bwd_request_floor(x01, meta) == want
