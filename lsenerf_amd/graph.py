@@ -121,10 +121,14 @@ class GraphedTrainStep:
 
     def __init__(self, model, opt: FlatAdam, col: Optional[RayBundle], prev: Optional[RayBundle], nxt: Optional[RayBundle],
                  batch: Dict[str, object], ray_grads: bool = False, jitter: str = "graph", warmup: int = 3,
-                 grad_scale: float = 1.0, prefetch_march: bool = False, prefetch_fork: str = "hash_bwd"):
+                 grad_scale: float = 1.0, prefetch_march: bool = False, prefetch_fork: str = "hash_bwd",
+                 optimizer_in_graph: bool = True):
         assert jitter in ("graph", "input")
         assert model.training, "the captured step is the training step"
         self.model, self.opt, self.grad_scale = model, opt, grad_scale
+        # False: the graph ends with the backward pass and the caller finishes the step -- data parallel: all-reduce of
+        # opt.flat.grad (lsenerf_amd.dist), then opt.step(grad_scale=1 / world) -- two more launches instead of ~25
+        self.optimizer_in_graph = bool(optimizer_in_graph)
         self._deferred_before = (model.deferred_counts, model.deferred_max_slots)
         model.deferred_counts, model.deferred_max_slots = True, 1 << 62     # nothing inside the graph may wait for the host
         self.col, self.prev, self.nxt = (_static_like(b, ray_grads) for b in (col, prev, nxt))
@@ -182,7 +186,8 @@ class GraphedTrainStep:
         out, losses, _ = self.model.train_step_bundles(self.col, self.prev, self.nxt, self.batch, jitter=self.jitter,
                                                        premarched=premarched)
         sum(losses.values()).backward()
-        self.opt.step_staged(self.grad_scale)
+        if self.optimizer_in_graph:
+            self.opt.step_staged(self.grad_scale)
         self.losses, self.outputs = losses, out
 
     def _body_prefetch(self, x: int):
@@ -254,7 +259,8 @@ class GraphedTrainStep:
                 raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
         if self.prefetch:
             return self._replay_prefetch(next_bundles, next_jitter)
-        self.opt.prepare_step()
+        if self.optimizer_in_graph:
+            self.opt.prepare_step()
         self.graph.replay()
         self.replays += 1
         return self.losses
@@ -277,7 +283,8 @@ class GraphedTrainStep:
             elif next_jitter is not None:
                 raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
         version = est.grid_version                 # (the grid cannot change while the replay runs: refreshes are eager, in order)
-        self.opt.prepare_step()
+        if self.optimizer_in_graph:
+            self.opt.prepare_step()
         self._graphs[x].replay()
         self.replays += 1
         self._pm_version = version if next_bundles is not None else None

@@ -3,7 +3,8 @@ R:train.py:104,146-167) with the REAL HIP model on two ranks.  The ranks are fre
 launches from pytest_configure -- before this pytest process makes its first GPU call, because ranks must never be spawned
 from a process that has initialised the GPU -- running tools/dp_rehearsal.py: 2 x 2048 rays, the reference's default
 configuration (visibility pre-pass on, 4-level 128^3 grid), occupancy refresh at steps 0 and 320, three optimizer steps, for the
-plain / pipelined / sharded / overlap exchanges of lsenerf_amd.dist, against ONE process on the full 4096-ray batch.  A one-GPU
+plain / pipelined / sharded / overlap exchanges of lsenerf_amd.dist and the step replayed as a HIP graph up to the backward pass
+with the exchange and Adam behind it ("graphed"), against ONE process on the full 4096-ray batch.  A one-GPU
 box cannot host two RCCL ranks, so the two-rank collectives run over gloo.  The RCCL calls themselves (async all_reduce on slices
 of the flat buffer, reduce_scatter_tensor / all_gather_into_tensor of the sharded Adam, broadcasts of the float and bool grids)
 are executed by a second child: ONE rank over backend "nccl" with every collective forced (dist.SINGLE_RANK_COLLECTIVES) -- each
@@ -13,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-MODES = ("plain", "pipelined", "sharded", "overlap")
+MODES = ("plain", "pipelined", "sharded", "overlap", "graphed")
 
 
 def _report(r):

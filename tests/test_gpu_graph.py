@@ -205,3 +205,31 @@ def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_ea
     assert marched_again == [True, False, False, True, False, True]        # first call, refresh, nothing announced
     step.check_overflow()
     step.close()
+
+
+def test_graph_without_the_optimizer_leaves_exchange_and_update_to_the_caller():
+    """optimizer_in_graph=False (data parallel: the all-reduce of the flat gradient sits between the backward pass and Adam): the
+    replay leaves this rank's gradient in opt.flat.grad and updates nothing; the caller's exchange + opt.step() finish the step.
+    Same losses, gradients and step counts as the eager step."""
+    from lsenerf_amd.graph import GraphedTrainStep
+    (m_e, m_g), (o_e, o_g), batch_of = _setup(False)
+    b0, batch0, jit0 = batch_of(50)
+    step = GraphedTrainStep(m_g, o_g, *b0, batch0, jitter="input", optimizer_in_graph=False)
+    spans = [(o, o + p.numel()) for p, o in zip(o_e.flat.params, o_e.flat.offsets)]
+    for it in range(3):
+        bundles, batch, jit = batch_of(60 + 10 * it)
+        before = o_g.flat.data.clone()
+        l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit).items()}
+        assert torch.equal(o_g.flat.data, before) and o_g.step_count == it          # the replay updated nothing
+        g_g = o_g.flat.grad.clone()
+        # (data parallel: lsenerf_amd.dist.allreduce_grads(o_g.flat.grad) here, then the update with grad_scale = 1 / world)
+        o_g.step(grad_scale=1.0)
+        l_e, g_e, _ = _eager_step(m_e, o_e, bundles, batch, jit, False)
+        for k in l_e:
+            assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (it, k, l_g[k], l_e[k])
+        if it == 0:
+            for a, b in spans:
+                assert nmax_err(g_g[a:b], g_e[a:b], 1e-12) < 3e-5, (a, b)
+        assert o_g.step_count == o_e.step_count == it + 1
+    step.check_overflow()
+    step.close()

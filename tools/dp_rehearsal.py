@@ -9,8 +9,9 @@ parameters must equal those of ONE process trained on the whole batch.
 
 For every exchange of lsenerf_amd.dist -- plain (one blocking all-reduce), pipelined (GradPipeline: all-reduce + Adam
 finished behind the next step's ray marcher, before the visibility pre-pass reads the parameters), sharded
-(reduce-scatter -> Adam on 1/W -> all-gather) and overlap (two-launch hash backward, early all-reduce of the fine levels)
--- the script runs: occupancy refresh at step 0 (warm-up branch: all cells), 3 train steps in the reference's default
+(reduce-scatter -> Adam on 1/W -> all-gather), overlap (two-launch hash backward, early all-reduce of the fine levels) and
+graphed (sampler ... backward replayed as ONE HIP graph per rank, lsenerf_amd.graph.GraphedTrainStep(optimizer_in_graph=False),
+then the plain all-reduce and Adam) -- the script runs: occupancy refresh at step 0 (warm-up branch: all cells), 3 train steps in the reference's default
 configuration (cone 0.004, alpha_thre 0.01 => sigma_fn pre-pass on, 4-level 128^3 grid), occupancy refresh at step 320
 (sampled branch), and asserts
   * the first step's rank-averaged gradient == the single-process full-batch gradient within 3e-6 * max|g| per parameter
@@ -129,6 +130,8 @@ def run(mode: str, rank: int, world: int, dev, batch):
                    camera_indices=torch.zeros(sl.stop - sl.start, 1, dtype=torch.long, device=dev),
                    metadata={"appearance_id": batch["aid"][sl]})
     grids_ok, pre_sync = [], []
+    fused_batch = {"col_batch": {"image": batch["target"][sl]}, "evs_batch": None}
+    graphed = None
 
     def refresh_grid(step):
         # the refresh reads the parameters: finish a pending exchange first.  The compute runs in turns; what
@@ -146,6 +149,10 @@ def run(mode: str, rank: int, world: int, dev, batch):
 
     refresh_grid(0)
     progress(rank, mode, "grid refreshed at step 0")
+    if mode == "graphed":
+        # everything up to and including the backward pass as ONE replayed HIP graph; all-reduce + Adam stay with the caller
+        from lsenerf_amd.graph import GraphedTrainStep
+        graphed = turns(lambda: GraphedTrainStep(model, opt, rb, None, None, fused_batch, jitter="input", optimizer_in_graph=False))
     n_samples = []
     first_grad = None
     for step in range(STEPS):
@@ -155,9 +162,13 @@ def run(mode: str, rank: int, world: int, dev, batch):
                 exchange.begin_step(1)
             # pipelined: sampling() fires GradPipeline.flush after the marcher and before the sigma_fn pre-pass (the all-reduce
             # it waits for was started by every rank in its previous turn)
+            if graphed is not None:            # backward pass included, optimizer not: the exchange below sits in between
+                graphed(rb, None, None, fused_batch, jitter=batch["jitter"][sl])
+                return int(graphed.outputs["col_out"]["num_samples_per_ray"].sum())
             out = model.exec_get_outputs(rb, jitter=batch["jitter"][sl])
             opt.zero_grad()
-            loss = torch.nn.functional.mse_loss(out["rgb"], batch["target"][sl])
+            # the training loss of the pipeline for a colour bundle: routing + rgb MSE in the fused epilogue (bench.py does the same)
+            loss = model.fused_loss_dict({"col_out": out, "prev_out": None, "next_out": None}, fused_batch)["rgb_loss"]
             loss.backward()
             n = int(out["num_samples_per_ray"].sum())
             if pipe is not None:
@@ -186,6 +197,9 @@ def run(mode: str, rank: int, world: int, dev, batch):
             turns(lambda: opt.step(grad_scale=1.0 / w))
     if pipe is not None:
         turns(pipe.flush)
+    if graphed is not None:
+        graphed.check_overflow()
+        graphed.close()
     refresh_grid(320)
     if exchange is not None:
         exchange.uninstall()
@@ -197,7 +211,7 @@ def run(mode: str, rank: int, world: int, dev, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dp_rehearsal.json"))
-    ap.add_argument("--modes", default="plain,pipelined,sharded,overlap")
+    ap.add_argument("--modes", default="plain,pipelined,sharded,overlap,graphed")
     ap.add_argument("--concurrent", action="store_true", help="all ranks compute at the same time on the shared GPU")
     ap.add_argument("--backend", default="gloo", help='"nccl": ONE rank over RCCL with every collective forced '
                     "(lsenerf_amd.dist.SINGLE_RANK_COLLECTIVES): executes the RCCL calls of each exchange on HIP tensors")
