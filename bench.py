@@ -506,6 +506,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the default-config / M-packed context runs")
+    ap.add_argument("--no-atomic-floor", action="store_true",
+                    help="skip roofline.atomic (its request count sorts 16 x 8 x N indices with torch kernels AFTER the timed region: "
+                         "left out of rocprofv3 passes so that the kernel statistics hold the step's kernels only)")
     args = ap.parse_args()
 
     from lsenerf_amd import _lib, ops, dist as ldist
@@ -601,7 +604,7 @@ def main():
         except OSError:
             pass
         atomic = None
-        if dom == "lse_hash_bwd":
+        if dom == "lse_hash_bwd" and not args.no_atomic_floor:
             # second roofline of the dominant kernel: it scatters with float atomics, which gfx950 executes at the memory side at a
             # chip-wide REQUEST rate (MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of 64-byte requests = ~20 G requests/s;
             # tools/micro/atomic_gran.hip: 21 G/s), far below the HBM byte rate the contract's `frac` is priced against

@@ -10,11 +10,11 @@ timeout -k 10 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; rc=$?; 
 if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 600 python bench.py > $OUT/bench.log 2>&1; rc=$?; echo "bench rc=$rc"; tail -3 $OUT/bench.log | cut -c1-1800
 if [ $rc -ne 0 ]; then exit $rc; fi
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-context > $OUT/rocprof.log 2>&1; rc=$?
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-context --no-atomic-floor > $OUT/rocprof.log 2>&1; rc=$?
 echo "rocprof rc=$rc"; find $OUT/prof -name "*kernel_stats*" | head
 # HBM traffic counters: separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-context > $OUT/pmc_$C.log 2>&1; rc=$?
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-context --no-atomic-floor > $OUT/pmc_$C.log 2>&1; rc=$?
   echo "pmc $C rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 done
 find $OUT -name "*counter_collection*" | head
