@@ -604,7 +604,7 @@ def main():
         except OSError:
             pass
         atomic = None
-        if dom == "lse_hash_bwd" and not args.no_atomic_floor:
+        if dom == "lse_hash_bwd" and not args.no_atomic_floor and world == 1:      # (N = 1 only, like cpu_baseline: rank 0 alone would lag the others)
             # second roofline of the dominant kernel: it scatters with float atomics, which gfx950 executes at the memory side at a
             # chip-wide REQUEST rate (MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of 64-byte requests = ~20 G requests/s;
             # tools/micro/atomic_gran.hip: 21 G/s), far below the HBM byte rate the contract's `frac` is priced against
