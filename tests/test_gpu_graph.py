@@ -207,19 +207,22 @@ def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_ea
     step.close()
 
 
-def test_graph_without_the_optimizer_leaves_exchange_and_update_to_the_caller():
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_graph_without_the_optimizer_leaves_exchange_and_update_to_the_caller(prefetch):
     """optimizer_in_graph=False (data parallel: the all-reduce of the flat gradient sits between the backward pass and Adam): the
     replay leaves this rank's gradient in opt.flat.grad and updates nothing; the caller's exchange + opt.step() finish the step.
     Same losses, gradients and step counts as the eager step."""
     from lsenerf_amd.graph import GraphedTrainStep
     (m_e, m_g), (o_e, o_g), batch_of = _setup(False)
     b0, batch0, jit0 = batch_of(50)
-    step = GraphedTrainStep(m_g, o_g, *b0, batch0, jitter="input", optimizer_in_graph=False)
+    step = GraphedTrainStep(m_g, o_g, *b0, batch0, jitter="input", optimizer_in_graph=False, prefetch_march=prefetch)
     spans = [(o, o + p.numel()) for p, o in zip(o_e.flat.params, o_e.flat.offsets)]
+    steps = [batch_of(60 + 10 * it) for it in range(4)]
     for it in range(3):
-        bundles, batch, jit = batch_of(60 + 10 * it)
+        bundles, batch, jit = steps[it]
         before = o_g.flat.data.clone()
-        l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit).items()}
+        kw = {"next_bundles": steps[it + 1][0], "next_jitter": steps[it + 1][2]} if prefetch else {}
+        l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit, **kw).items()}
         assert torch.equal(o_g.flat.data, before) and o_g.step_count == it          # the replay updated nothing
         g_g = o_g.flat.grad.clone()
         # (data parallel: lsenerf_amd.dist.allreduce_grads(o_g.flat.grad) here, then the update with grad_scale = 1 / world)
