@@ -322,6 +322,17 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
                         const uint64_t rest = occ_mask >> b;
                         const int run = rest ? min((int)__builtin_ctzll(rest), nb - b) : nb - b;
                         b += run - 1;
+                    } else {
+                        // A run of OCCUPIED cells is marched against its last boundary as well: inside the run a cell ends either
+                        // because the next sample's mid-point has reached the cell's boundary -- the following cell then makes the
+                        // same test against its own, later boundary and emits that very sample -- or because the sample's end has
+                        // reached the boundary, where the following cell simply continues from that end.  Either way the samples
+                        // and the final t are those of marching against the last boundary of the run; `continuous` stays set from
+                        // the first emitted sample on.  (Round 3: the metric workload's fully occupied grid is one run per batch,
+                        // so the vector march fills its 64 lanes instead of emitting the 5 - 8 samples of one cell.)
+                        const uint64_t rest = ~(occ_mask >> b);
+                        const int run = min((int)__builtin_ctzll(rest | (1ull << 63)), nb - b);
+                        b += run - 1;
                     }
                     const float t_traverse = s_tt[b];
                     if (CONST_DT && a.vec_march &&
