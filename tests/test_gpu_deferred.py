@@ -137,3 +137,52 @@ def test_train_step_bundles_deferred_equals_synced():
     for k in ("col_out", "prev_out", "next_out"):
         assert torch.equal(o0[k]["rgb"], o1[k]["rgb"]) and torch.equal(o0[k]["num_samples_per_ray"], o1[k]["num_samples_per_ray"])
     assert nmax_err(g1, g0, 1e-12) < 3e-5
+
+
+def test_samples_marched_ahead_of_the_step_are_the_steps_own_samples():
+    """LSEOccGridEstimator.march_deferred / LSENeRFModel.premarch_bundles: the marcher launched ahead of its step (it reads rays and
+    grid only) and handed back through ``premarched=`` must give the render of the step that marches for itself, bit for bit;
+    reused buffers (``out=``) are overwritten in place and refused when they do not fit; ``grid_version`` moves with every change
+    of the grid made through the estimator."""
+    from lsenerf_amd import RayBundle, _lib, ops
+    m = _model()
+    est = m.occupancy_grid
+    R = 200
+    g = torch.Generator().manual_seed(2)
+
+    def bundle(seed, n):
+        o, d = random_rays(n, seed=seed)
+        return RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"),
+                         metadata={"appearance_id": torch.randint(0, 16, (n,), generator=g).cuda()})
+    col, prev, nxt = bundle(4, R), bundle(5, 40), bundle(6, 40)
+    jit = torch.rand(R + 80, generator=g).cuda()
+    batch = {"col_batch": {"image": torch.rand(R, 3, generator=g).cuda()}, "evs_batch": {"image": torch.rand(40, 1, generator=g).cuda() - 0.5}}
+    out_ref, loss_ref, _ = m.train_step_bundles(col, prev, nxt, batch, jitter=jit)
+    pm = m.premarch_bundles(col, prev, nxt, jitter=jit)
+    assert pm.n_rays == R + 80 and pm.grid_version == est.grid_version and int(pm.n_dev) > 20 * R
+    out_pm, loss_pm, _ = m.train_step_bundles(col, prev, nxt, batch, premarched=pm)            # (jitter was applied by the marcher)
+    for k in ("col_out", "prev_out", "next_out"):
+        for key in ("rgb", "depth", "accumulation", "num_samples_per_ray"):
+            assert torch.equal(out_pm[k][key], out_ref[k][key]), (k, key)
+    assert all(torch.equal(loss_pm[k], loss_ref[k]) for k in loss_ref)
+    # the same buffers filled again for other rays: in place, same tensors
+    col2 = bundle(14, R)
+    ptrs = [t.data_ptr() for t in pm[:6]]
+    pm2 = m.premarch_bundles(col2, prev, nxt, jitter=jit, out=pm)
+    assert [t.data_ptr() for t in pm2[:6]] == ptrs
+    ref2, _, _ = m.train_step_bundles(col2, prev, nxt, batch, jitter=jit)
+    got2, _, _ = m.train_step_bundles(col2, prev, nxt, batch, premarched=pm2)
+    assert torch.equal(got2["col_out"]["rgb"], ref2["col_out"]["rgb"])
+    with pytest.raises(_lib.LseHipError, match="not a result"):
+        m.premarch_bundles(col, None, None, jitter=jit[:R], out=pm)                            # other ray count: other capacity
+    with pytest.raises(ValueError, match="premarched samples are for"):
+        m.train_step_bundles(col, None, None, {"col_batch": batch["col_batch"], "evs_batch": None}, premarched=pm2)
+    # grid_version follows the grid
+    v0 = est.grid_version
+    m.update_occupancy_grid(0)
+    assert est.grid_version == v0 + 1
+    est.mark_all_occupied()
+    assert est.grid_version == v0 + 2
+    m.update_occupancy_grid(5)            # not a refresh step: nothing changes
+    assert est.grid_version == v0 + 2
+    est.check_deferred_overflow()
