@@ -183,7 +183,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
  *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
- *   second_probe  impl 1, 2: extra probe rounds in the neighbouring slots before a corner falls back to memory (default 1)
+ *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3, run-time option "hash_bwd_probes")
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)
  *   coarse_levels the levels below this one are processed first by a cache-free kernel at high occupancy (lane = sample, run
@@ -226,6 +226,8 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
  *                       arithmetic routes differ in the last bits (both within f32 rounding of the exact result)
  *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
  *                       MFMAs; default), 0 = first-generation kernel
+ *   "mlp_bwd3_cfg"      CT * 100 + NW of the third-generation fused backward (default 208; 112, 108, 204 = A/B partners)
+ *   "hash_bwd_probes"   default of lse_hash_bwd_opts.second_probe (3): probe rounds of the backward's sector cache
  *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
  *   "traverse_fma"      0 (default) = every product and sum of the traversal set-up rounded separately (bit-exact against
  *                       oracle/c/liblse_oracle.so); 1 = the a*b+c sites of nerfacc's grid.cu (ray start / end, the two products of

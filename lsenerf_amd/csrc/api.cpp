@@ -26,6 +26,7 @@ static Option g_options[] = {
     {"mlp_fwd_impl", {2}},
     {"mlp_bwd3_cfg", {208}},
     {"mlp_act_nt", {0}},
+    {"hash_bwd_probes", {3}},
     {"traverse_vec", {1}},
     {"traverse_fma", {0}},
 };

@@ -862,15 +862,18 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     to_mem[c] = act && !okc[c];
                 }
                 for (int pr = 0; pr < second_probe; ++pr) {
-                    // another chance in the next slot for the corners that lost the previous one (batched the same way)
+                    // another chance in the next slot for the corners that lost the previous one (batched the same way); a loser keeps
+                    // its home slot, so round pr probes home + (pr + 1) * kStep (until round 3 every round after the first probed the
+                    // same neighbour again and could not win anything)
                     bool any = false;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) any = any || to_mem[c];
                     if (__builtin_amdgcn_ballot_w64(any) != 0) {
                         uint32_t old2[8];
+                        const uint32_t hop = (uint32_t)(pr + 1) * kStep;
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + kStep) & (kSlots - 1)] : dummy32, kNoLine,
+                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + hop) & (kSlots - 1)] : dummy32, kNoLine,
                                               to_mem[c] ? (gi[c] >> kEntLog2) : kNoLine);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
@@ -880,12 +883,12 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                                 if (cm) {
                                     if (claim)
                                         list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                            (uint16_t)((slot[c] + kStep) & (kSlots - 1));
+                                            (uint16_t)((slot[c] + hop) & (kSlots - 1));
                                     used += __builtin_popcountll(cm);
                                 }
                             }
                             if (claim || (to_mem[c] && old2[c] == (gi[c] >> kEntLog2))) {
-                                slot[c] = (slot[c] + kStep) & (kSlots - 1);
+                                slot[c] = (slot[c] + hop) & (kSlots - 1);
                                 okc[c] = true;
                                 to_mem[c] = false;
                             }
@@ -1391,8 +1394,11 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
                            // flush, 2 = unpaired); impl 1: 2 / 3
     o->few_runs = 6;       // round 3 (replicas took the contention out of the direct adds): default configuration 1.60 -> 1.53 ms,
                            // M-march 2.62 -> 2.62, M-packed 3.17 -> 3.20; 8: 1.51 / 2.63 / 3.28; 16: slower everywhere
-    o->second_probe = 1;   // extra probe rounds (next slot) before a corner goes to memory alone; pays wherever the kernel is
-                           // bound by atomic requests (sphere rays 4.27 -> 3.86 ms), costs ~2 % where it is issue-bound
+    o->second_probe = (int32_t)lse::option("hash_bwd_probes");   // extra probe rounds (home + k * step) before a corner goes to memory
+                           // alone; pays wherever the kernel is bound by atomic requests, costs ~2 % per round where it is issue-bound.
+                           // 1 -> 3 rounds (round 3, once the later rounds probed NEW slots): requests 50.5 -> 48.2 M (metric size),
+                           // 28.3 -> 26.9 M (default configuration); hash_bwd 2.66 -> 2.66 / 1.40 -> 1.34 / 1.13 -> 1.05 ms (metric size /
+                           // default configuration / 3-bundle step), M-packed step 6.07 -> 5.99; 4 rounds: slower everywhere
     o->rounds = 32;
     o->dbg = 0;
     o->interleave_from_scale = 1e30f;   // measured negative on MI355X (same-address lanes of one atomic instruction serialise)

@@ -322,7 +322,7 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
     dy = w.reshape(N, 16, 2).permute(1, 0, 2).contiguous().cuda()          # level-major, as the fused MLP hands it over
     xg, tg = x.cuda(), table.cuda()
     bounds = hash_level_bounds(meta)
-    variants = {"default": {}, "unpaired_sectors": {"gran": 2}, "paired_probe2": {"gran": 4, "second_probe": 2}, "stage_all": {"stage_max": 64}, "stage_none": {"stage_max": 0}, "batched_probe0": {"second_probe": 0}, "batched_probe3": {"second_probe": 3},
+    variants = {"default": {}, "unpaired_sectors": {"gran": 2}, "paired_probe2": {"gran": 4, "second_probe": 2}, "stage_all": {"stage_max": 64}, "stage_none": {"stage_max": 0}, "batched_probe0": {"second_probe": 0}, "batched_probe1": {"second_probe": 1}, "batched_probe5": {"second_probe": 5},
                 "batched_no_few_runs": {"few_runs": 0}, "per_level_pass": {"impl": 1}, "line_cache": {"impl": 1, "gran": 3},
                 "second_probe": {"impl": 1, "second_probe": 1}, "no_few_runs": {"impl": 1, "few_runs": 0},
                 "lanes16": {"impl": 0}, "lanes16_r64": {"impl": 0, "rounds": 64},

@@ -33,7 +33,7 @@ def test_runtime_options_and_hash_bwd_opts_without_gpu():
     """Tuning knobs are call arguments (lse_hash_bwd_ex) or run-time options -- no process-lifetime environment statics."""
     from lsenerf_amd import _lib
     o = _lib.hash_bwd_default_opts()
-    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 6, 1, 32, 0, 16, 0)
+    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 6, 3, 32, 0, 16, 0)
     assert (o.replicas, o.replica_levels, o.prefetch, o.workspace) == (16, 4, 0, None)
     assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28 and _lib.get_option("traverse_fma") == 0
     _lib.set_option("mlp_fwd_cfg", 44)
