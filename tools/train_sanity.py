@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end sanity of the training path: a student field is fitted to renders of a teacher field (synthetic scene, the reference's
 default sampler configuration, occupancy refresh every 16 steps, colour + event bundles through train_step_bundles) for a few hundred
-steps, once with the eager step and once with the captured step (lsenerf_amd.graph.GraphedTrainStep).  Prints the loss curve of both;
-they must fall together (same rays, same targets; the jitter streams differ).  usage: python tools/train_sanity.py [steps]"""
+steps, once with the eager step, once with the captured step (lsenerf_amd.graph.GraphedTrainStep) and once with the captured step that
+marches the next step's rays on a side stream.  Prints the loss curves; they must fall together (same rays, same targets; the jitter streams differ).  usage: python tools/train_sanity.py [steps]"""
 import json
 import os
 import sys
@@ -58,7 +58,7 @@ def batch_of(it):
 
 
 results = {}
-for mode in ("eager", "graphed"):
+for mode in ("eager", "graphed", "graphed_prefetch"):
     torch.manual_seed(2)
     student = LSENeRFModel(LSENeRFModelConfig(**cfg), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(dev).train()
     opt = FlatAdam(FlatParams(student.get_param_groups()["fields"]), lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=20000)
@@ -69,7 +69,11 @@ for mode in ("eager", "graphed"):
     for it in range(STEPS):
         student.update_occupancy_grid(it)
         col, prev, nxt, batch = batch_of(it)
-        if mode == "eager":
+        if mode == "graphed_prefetch":      # the next step's rays are announced one step early and marched on the side stream
+            if step is None:
+                step = GraphedTrainStep(student, opt, col, prev, nxt, batch, prefetch_march=True)
+            losses = step(col, prev, nxt, batch, next_bundles=batch_of(it + 1)[:3])
+        elif mode == "eager":
             opt.zero_grad()
             _, losses, _ = student.train_step_bundles(col, prev, nxt, batch)
             sum(losses.values()).backward()
