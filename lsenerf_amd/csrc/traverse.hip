@@ -392,32 +392,46 @@ __global__ void fake_sample_kernel(int64_t *__restrict__ packed, int64_t *__rest
     }
 }
 
-// single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total
+// single-workgroup exclusive scan of int64 counts -> packed_info[R,2] and total.  Every thread sums a contiguous run of counts, the
+// 64 partial sums of a wave are scanned with lane shuffles, the 16 wave totals by the first wave: two workgroup barriers instead of the
+// twenty of a Hillis-Steele scan over 1024 LDS entries.  (The launch stays at ~8 us -- one workgroup, two dependent trips to memory --
+// of which the scan was the smaller part: 9.2 -> 8.5 us for 4096 rays.)
 __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t *__restrict__ cnts, int n, int64_t *packed,
                                                          int64_t *total)
 {
-    __shared__ int64_t part[1024];
-    const int t = threadIdx.x;
+    __shared__ int64_t wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (n + 1023) / 1024;
-    const int lo = t * per, hi = min(n, lo + per);
+    const int lo = min(n, t * per), hi = min(n, lo + per);
     int64_t s = 0;
     for (int i = lo; i < hi; ++i) s += cnts[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int64_t v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    // inclusive scan of the 64 partial sums of this wave
+    int64_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    int64_t run = part[t] - s;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int64_t w = lane < 16 ? wave_tot[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int64_t v = __shfl_up(w, off, 64);
+            if (lane >= off) w += v;
+        }
+        if (lane < 16) wave_tot[lane] = w;      // inclusive totals of waves 0 .. lane
+    }
+    __syncthreads();
+    int64_t run = (wave ? wave_tot[wave - 1] : 0) + incl - s;
     for (int i = lo; i < hi; ++i) {
         const int64_t c = cnts[i];
         packed[2 * i] = run;
         packed[2 * i + 1] = c;
         run += c;
     }
-    if (t == 1023 && total) *total = part[1023];
+    if (t == 1023 && total) *total = wave_tot[15];
 }
 
 // Packs the per-ray slots of the single-pass marcher: one wave per ray copies its count samples to the packed position.
