@@ -227,7 +227,8 @@ int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy
  *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
  *                       MFMAs; default), 0 = first-generation kernel
  *   "mlp_bwd3_cfg"      CT * 100 + NW of the third-generation fused backward (default 208; 112, 108, 204 = A/B partners)
- *   "hash_bwd_probes"   default of lse_hash_bwd_opts.second_probe (3): probe rounds of the backward's sector cache
+ *   "hash_bwd_probes" / "hash_bwd_few_runs" / "hash_bwd_stage_max"   defaults of lse_hash_bwd_opts.second_probe (3: probe rounds of
+ *                       the backward's sector cache), .few_runs (6) and .stage_max (16), for A/B runs of whole steps
  *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
  *   "traverse_fma"      0 (default) = every product and sum of the traversal set-up rounded separately (bit-exact against
  *                       oracle/c/liblse_oracle.so); 1 = the a*b+c sites of nerfacc's grid.cu (ray start / end, the two products of

@@ -27,6 +27,8 @@ static Option g_options[] = {
     {"mlp_bwd3_cfg", {208}},
     {"mlp_act_nt", {0}},
     {"hash_bwd_probes", {3}},
+    {"hash_bwd_few_runs", {6}},
+    {"hash_bwd_stage_max", {16}},
     {"traverse_vec", {1}},
     {"traverse_fma", {0}},
 };

@@ -1394,10 +1394,11 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
 {
     if (!o) return;
     o->impl = 2;           // lane-per-sample + LDS sector cache, run ends of several levels batched per cache pass
-    o->stage_max = 16;     // impl 2: a level ending more runs than this per wave passes unstaged when the queue is empty
+    o->stage_max = (int32_t)lse::option("hash_bwd_stage_max");   // impl 2: a level ending more runs than this per wave passes unstaged
+                           // when the queue is empty
     o->gran = 6;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line, second-generation flush (4 = first-generation
                            // flush, 2 = unpaired); impl 1: 2 / 3
-    o->few_runs = 6;       // round 3 (replicas took the contention out of the direct adds): default configuration 1.60 -> 1.53 ms,
+    o->few_runs = (int32_t)lse::option("hash_bwd_few_runs");     // round 3 (replicas took the contention out of the direct adds): default configuration 1.60 -> 1.53 ms,
                            // M-march 2.62 -> 2.62, M-packed 3.17 -> 3.20; 8: 1.51 / 2.63 / 3.28; 16: slower everywhere
     o->second_probe = (int32_t)lse::option("hash_bwd_probes");   // extra probe rounds (home + k * step) before a corner goes to memory
                            // alone; pays wherever the kernel is bound by atomic requests, costs ~2 % per round where it is issue-bound.
