@@ -294,7 +294,8 @@ int lse_ray_features_bwd(const float *rays_d, const float *d_feat, const int32_t
 /* small dense helpers on per-ray matrices: y[R,M] = x[R,K] W[M,K]^T ; dx[R,K] = dy[R,M] W[M,K] ;
  * dW[M,K] += dy^T x. */
 /* The same features AND the per-ray share of the head's first layer in one launch:
- *   feat[R, in_pad] = [SH16 | 0 x 15 | emb (emb_dim) | ones padding],  in_pad = roundup(31 + emb_dim, 16)  (tcnn's layout)
+ *   feat[R, in_pad] = [SH16 | 0 x 15 | emb (emb_dim) | ones padding],  in_pad = roundup(31 + emb_dim, 16)  (tcnn's layout);
+ *   0 <= emb_dim <= 97 (the reference's LSEEmbeddingConfig.emb_dim, default 32: in_pad 64)
  *   row_bias[R, width] = feat * W_in^T with W_in[width][w_ld] the head's tcnn input matrix in place.
  * Backward: d_feat[R, in_pad] = d_row_bias * W_in (workspace, overwritten), d_rays_d[R,3] (nullable) through the SH
  * Jacobian, d_emb_table[n_emb_rows, emb_dim] (nullable, accumulate).  The weight gradient d W_in += d_row_bias^T feat is

@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__
 {
     // thread (part, col): 8 ray-partitions x 32 columns; the ray-id test is wave-uniform per iteration (all 32 column
     // lanes of a partition look at the same ray), partial sums stay in a register, one LDS pass combines the partitions.
+    // (embeddings wider than 32: blockIdx.z walks the 32-column blocks)
     __shared__ float red[8][32];
-    const int e = blockIdx.x, col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int e = blockIdx.x, lcol = threadIdx.x & 31, col = blockIdx.z * 32 + lcol, part = threadIdx.x >> 5;
     float acc = 0.f;
     // blockIdx.y splits the ray list further (more loads in flight chip-wide); partial sums meet in d_emb via atomics
     const int nsplit = 8 * gridDim.y;
@@ -268,12 +269,12 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float *__restrict__
     }
     for (; r < r1; ++r)
         if (eidx[r] == e && col < emb_dim) acc += dfeat[(int64_t)r * feat_ld + 31 + col];
-    red[part][col] = acc;
+    red[part][lcol] = acc;
     __syncthreads();
     if (part == 0 && col < emb_dim) {
         float s = 0.f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[p][col];
+        for (int p = 0; p < 8; ++p) s += red[p][lcol];
         atomicAdd(&d_emb[(int64_t)e * emb_dim + col], s);
     }
 }
@@ -300,14 +301,15 @@ __device__ __forceinline__ void ray_feat(const float *dirs, const float *emb, co
     for (int k = in_dim; k < in_pad; ++k) f[k] = 1.f;                               // tcnn pads network inputs with ones
 }
 
-template <int WIDTH>
+// PITCH = LDS row pitch: 65 for padded input widths up to 64 (the reference's 32-wide appearance embedding: 31 + 32 -> 64), 129 up to 128
+template <int WIDTH, int PITCH>
 __global__ __launch_bounds__(256) void ray_bias_fwd_kernel(const float *__restrict__ dirs, const float *__restrict__ emb,
                                                            const int32_t *__restrict__ eidx, int n_rays, int emb_dim,
                                                            int in_pad, const float *__restrict__ W /* [WIDTH][w_ld] */,
                                                            int w_ld, float *__restrict__ feat, float *__restrict__ row_bias)
 {
-    __shared__ float s_f[kRbRays][65];
-    __shared__ float s_w[WIDTH][65];
+    __shared__ float s_f[kRbRays][PITCH];
+    __shared__ float s_w[WIDTH][PITCH];
     const int in_dim = 31 + emb_dim;
     const int r0 = blockIdx.x * kRbRays;
     for (int e = threadIdx.x; e < WIDTH * in_pad; e += 256) s_w[e / in_pad][e % in_pad] = W[(e / in_pad) * w_ld + e % in_pad];
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void ray_bias_fwd_kernel(const float *__restri
 }
 
 // d_feat = d_row_bias * W_in  ->  d(directions) through the SH Jacobian, and the embedding slice [R, 32] for emb_grad_kernel
-template <int WIDTH>
+template <int WIDTH, int PITCH>
 __global__ __launch_bounds__(256) void ray_bias_bwd_kernel(const float *__restrict__ dirs, const float *__restrict__ d_rb,
                                                            int n_rays, int emb_dim, int in_pad,
                                                            const float *__restrict__ W, int w_ld,
@@ -336,8 +338,8 @@ __global__ __launch_bounds__(256) void ray_bias_bwd_kernel(const float *__restri
                                                            float *__restrict__ d_dirs /* nullable */)
 {
     __shared__ float s_g[kRbRays][WIDTH + 1];
-    __shared__ float s_w[WIDTH][65];
-    __shared__ float s_df[kRbRays][65];
+    __shared__ float s_w[WIDTH][PITCH];
+    __shared__ float s_df[kRbRays][PITCH];
     const int r0 = blockIdx.x * kRbRays;
     for (int e = threadIdx.x; e < WIDTH * in_pad; e += 256) s_w[e / in_pad][e % in_pad] = W[(e / in_pad) * w_ld + e % in_pad];
     for (int e = threadIdx.x; e < kRbRays * WIDTH; e += 256) {
@@ -477,17 +479,19 @@ extern "C" int lse_ray_bias_fwd(const float *rays_d, const float *emb_table, con
     LSE_REQUIRE(n_rays >= 0, "lse_ray_bias_fwd: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(rays_d && w_in && feat && row_bias, "lse_ray_bias_fwd: null pointer");
-    LSE_REQUIRE(emb_dim == 0 || emb_dim == 32, "lse_ray_bias_fwd: emb_dim must be 0 or 32 (got %d)", emb_dim);
+    LSE_REQUIRE(emb_dim >= 0 && emb_dim <= 97, "lse_ray_bias_fwd: emb_dim %d not in [0, 97] (padded input width <= 128)", emb_dim);
     LSE_REQUIRE(width == 32 || width == 64, "lse_ray_bias_fwd: width %d not in {32,64}", width);
     const int in_pad = (31 + emb_dim + 15) / 16 * 16;
     LSE_REQUIRE(w_ld >= in_pad, "lse_ray_bias_fwd: w_ld %d < padded input width %d", w_ld, in_pad);
     const dim3 grid((n_rays + kRbRays - 1) / kRbRays);
-    if (width == 64)
-        hipLaunchKernelGGL((ray_bias_fwd_kernel<64>), grid, dim3(256), 0, lse::as_stream(stream), rays_d, emb_table, emb_idx,
-                           n_rays, emb_dim, in_pad, w_in, w_ld, feat, row_bias);
-    else
-        hipLaunchKernelGGL((ray_bias_fwd_kernel<32>), grid, dim3(256), 0, lse::as_stream(stream), rays_d, emb_table, emb_idx,
-                           n_rays, emb_dim, in_pad, w_in, w_ld, feat, row_bias);
+#define LSE_RB_FWD(W, P)                                                                                                       \
+    hipLaunchKernelGGL((ray_bias_fwd_kernel<W, P>), grid, dim3(256), 0, lse::as_stream(stream), rays_d, emb_table, emb_idx, n_rays, \
+                       emb_dim, in_pad, w_in, w_ld, feat, row_bias)
+    if (width == 64 && in_pad <= 64) LSE_RB_FWD(64, 65);
+    else if (width == 64) LSE_RB_FWD(64, 129);
+    else if (in_pad <= 64) LSE_RB_FWD(32, 65);
+    else LSE_RB_FWD(32, 129);
+#undef LSE_RB_FWD
     return lse::check_launch("lse_ray_bias_fwd");
 }
 
@@ -499,21 +503,23 @@ extern "C" int lse_ray_bias_bwd(const float *rays_d, const int32_t *emb_idx, int
     LSE_REQUIRE(n_rays >= 0, "lse_ray_bias_bwd: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(rays_d && w_in && d_row_bias && d_feat, "lse_ray_bias_bwd: null pointer");
-    LSE_REQUIRE(emb_dim == 0 || emb_dim == 32, "lse_ray_bias_bwd: emb_dim must be 0 or 32 (got %d)", emb_dim);
+    LSE_REQUIRE(emb_dim >= 0 && emb_dim <= 97, "lse_ray_bias_bwd: emb_dim %d not in [0, 97] (padded input width <= 128)", emb_dim);
     LSE_REQUIRE(width == 32 || width == 64, "lse_ray_bias_bwd: width %d not in {32,64}", width);
     LSE_REQUIRE(!d_emb_table || (n_emb_rows > 0 && emb_idx), "lse_ray_bias_bwd: d_emb_table needs n_emb_rows and emb_idx");
     const int in_pad = (31 + emb_dim + 15) / 16 * 16;
     LSE_REQUIRE(w_ld >= in_pad, "lse_ray_bias_bwd: w_ld %d < padded input width %d", w_ld, in_pad);
     hipStream_t st = lse::as_stream(stream);
     const dim3 grid((n_rays + kRbRays - 1) / kRbRays);
-    if (width == 64)
-        hipLaunchKernelGGL((ray_bias_bwd_kernel<64>), grid, dim3(256), 0, st, rays_d, d_row_bias, n_rays, emb_dim, in_pad, w_in,
-                           w_ld, d_feat, d_rays_d);
-    else
-        hipLaunchKernelGGL((ray_bias_bwd_kernel<32>), grid, dim3(256), 0, st, rays_d, d_row_bias, n_rays, emb_dim, in_pad, w_in,
-                           w_ld, d_feat, d_rays_d);
+#define LSE_RB_BWD(W, P)                                                                                                       \
+    hipLaunchKernelGGL((ray_bias_bwd_kernel<W, P>), grid, dim3(256), 0, st, rays_d, d_row_bias, n_rays, emb_dim, in_pad, w_in, w_ld, \
+                       d_feat, d_rays_d)
+    if (width == 64 && in_pad <= 64) LSE_RB_BWD(64, 65);
+    else if (width == 64) LSE_RB_BWD(64, 129);
+    else if (in_pad <= 64) LSE_RB_BWD(32, 65);
+    else LSE_RB_BWD(32, 129);
+#undef LSE_RB_BWD
     if (d_emb_table && emb_dim > 0)
-        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows, 8), dim3(256), 0, st, d_feat, emb_idx, n_rays, emb_dim,
+        hipLaunchKernelGGL(emb_grad_kernel, dim3(n_emb_rows, 8, (emb_dim + 31) / 32), dim3(256), 0, st, d_feat, emb_idx, n_rays, emb_dim,
                            d_emb_table, in_pad);
     return lse::check_launch("lse_ray_bias_bwd");
 }

@@ -288,7 +288,9 @@ class LSEField(nn.Module):
             embd_config = embd_config or LSEEmbeddingConfig()
             self.embedding_appearance = embd_config.setup(num_imgs=num_images, num_dims=appearance_embedding_dim)
             self.appearance_embedding_dim = self.embedding_appearance.get_emb_dim()
-            assert self.appearance_embedding_dim == 32, "per-ray feature kernel packs a 32-wide embedding"
+            if not 0 < self.appearance_embedding_dim <= 97:
+                raise ValueError(f"appearance_embedding_dim {self.appearance_embedding_dim}: the per-ray feature kernels take 1 .. 97 "
+                                 "(head input 16 + 15 + emb padded to at most 128 columns)")
         else:
             self.embedding_appearance = None
 

@@ -723,8 +723,12 @@ class _RayBiasFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             direct_w = _direct_grad(head_params)
             d_params = direct_w if direct_w is not None else torch.zeros_like(head_params)
-            _lib.call("lse_gemm_tn_acc", _f32(d_rb, "d_row_bias"), width, _f32(feat, "feat"), in_pad, _lib.LSE_IN_ROWMAJOR, R,
-                      ctypes.c_void_p(d_params.data_ptr()), in_pad, _stream())
+            if in_pad in (16, 32, 64):
+                _lib.call("lse_gemm_tn_acc", _f32(d_rb, "d_row_bias"), width, _f32(feat, "feat"), in_pad, _lib.LSE_IN_ROWMAJOR, R,
+                          ctypes.c_void_p(d_params.data_ptr()), in_pad, _stream())
+            else:       # other embedding widths (padded input 48, 80 .. 128): a plain [width x R] x [R x in_pad] library GEMM, per ray
+                with torch.no_grad():
+                    d_params[: width * in_pad].view(width, in_pad).addmm_(d_rb.t(), feat)
         return (d_dirs, None if direct_emb is not None else d_emb, None,
                 None if direct_w is not None else d_params, None)
 

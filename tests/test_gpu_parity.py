@@ -747,6 +747,36 @@ def test_mlp_config1_shapes():
 
 
 # ------------------------------------------------------------------------------------------------ SH / per-ray features
+@pytest.mark.parametrize("emb_dim", [8, 16, 32, 48, 97])
+def test_ray_bias_takes_other_embedding_widths(emb_dim):
+    """lse_ray_bias_fwd / _bwd with appearance embeddings other than the reference's 32 columns (padded head input 48 .. 128):
+    row_bias = [SH16 | 0 x 15 | emb[idx] | ones-padding] W_in^T and its gradients w.r.t. directions, embedding rows and W_in against
+    float64 autograd."""
+    from oracle.field import sh4_tcnn
+    ops = _ops()
+    R, width = 300, 64
+    in_pad = (31 + emb_dim + 15) // 16 * 16
+    _, d = random_rays(R, seed=emb_dim)
+    g = torch.Generator().manual_seed(emb_dim)
+    emb = torch.randn(5, emb_dim, generator=g)
+    idx = torch.randint(0, 5, (R,), generator=g)
+    head = torch.randn(width * in_pad + 2 * width * width, generator=g) * 0.3      # W_in first, the rest of the head's parameters behind it
+    gout = torch.randn(R, width, generator=g)
+    dc, ec, wc = (t.double().clone().requires_grad_(True) for t in (d, emb, head))
+    feat = torch.cat([sh4_tcnn((dc + 1) / 2), torch.zeros(R, 15, dtype=torch.float64), ec[idx],
+                      torch.ones(R, in_pad - 31 - emb_dim, dtype=torch.float64)], -1)
+    ref = feat @ wc[: width * in_pad].view(width, in_pad).t()
+    (ref * gout.double()).sum().backward()
+    dg, eg, wg = (t.clone().cuda().requires_grad_(True) for t in (d, emb, head))
+    out = ops.ray_bias(dg, eg, idx.int().cuda(), wg, width)
+    assert out.shape == (R, width) and nmax_err(out, ref.float()) < TOL_FWD
+    (out * gout.cuda()).sum().backward()
+    assert nmax_err(dg.grad, dc.grad.float()) < TOL_GRAD
+    assert nmax_err(eg.grad, ec.grad.float()) < TOL_GRAD
+    assert nmax_err(wg.grad, wc.grad.float()) < TOL_GRAD
+    assert float(wg.grad[width * in_pad:].abs().max()) == 0.0
+
+
 def test_ray_features_and_linear():
     from oracle.field import sh4_tcnn
     ops = _ops()
@@ -902,6 +932,20 @@ def test_model_end_to_end_default_config(emb_type):
     aid = torch.randint(0, 8, (96,), generator=torch.Generator().manual_seed(2)) if emb_type == "evs_emb" else None
     res = compare_model_outputs(hip, orc, o, d, aid, check_grads=True)
     assert res["n_samples"] > 2000
+
+
+@pytest.mark.parametrize("emb_dim", [16, 48])
+def test_model_end_to_end_other_embedding_width(emb_dim):
+    """LSEEmbeddingConfig.emb_dim (R:lse_nerf/lse_embeddings.py:94-107) other than the default 32: the head's padded input is 48 / 80
+    columns wide; renders and every gradient (hash table, both MLPs, embedding rows, rays) against the oracle."""
+    from tests.util import compare_model_outputs, make_model_pair
+    hip, orc = make_model_pair(grid_levels=2, grid_resolution=32, occupied_frac=0.4, emb_type="evs_emb", param_scale=300.0,
+                               alpha_thre=0.0, emb_dim=emb_dim)
+    assert hip.field.mlp_head.in_pad == (31 + emb_dim + 15) // 16 * 16
+    o, d = random_rays(96, seed=22)
+    aid = torch.randint(0, 8, (96,), generator=torch.Generator().manual_seed(3))
+    res = compare_model_outputs(hip, orc, o, d, aid, check_grads=True)
+    assert res["n_samples"] > 1000
 
 
 def test_model_config1_small_field():

@@ -120,7 +120,7 @@ def random_binaries(levels: int, res: int, frac: float, seed: int = 0) -> torch.
 
 def make_model_pair(grid_levels=4, grid_resolution=128, seed=96, occupied_frac=0.3, num_levels=16, hidden=64,
                     emb_type="global_emb", num_train_data=8, contraction=True, alpha_thre=0.01, cone_angle=0.004,
-                    log2_hashmap_size=19, param_scale: float = 1.0):
+                    log2_hashmap_size=19, param_scale: float = 1.0, emb_dim: int = 32):
     """(HIP model on cuda:0, ModelOracle on CPU) sharing parameters, occupancy grid and hyper-parameters."""
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, LSEEmbeddingConfig
     from oracle.field import FieldOracle
@@ -130,7 +130,7 @@ def make_model_pair(grid_levels=4, grid_resolution=128, seed=96, occupied_frac=0
     cfg = LSENeRFModelConfig(grid_levels=grid_levels, grid_resolution=grid_resolution, num_levels=num_levels,
                              hidden_dim=hidden, hidden_dim_color=hidden, alpha_thre=alpha_thre, cone_angle=cone_angle,
                              log2_hashmap_size=log2_hashmap_size, disable_scene_contraction=not contraction,
-                             embed_config=LSEEmbeddingConfig(embedding_type=emb_type))
+                             embed_config=LSEEmbeddingConfig(embedding_type=emb_type, emb_dim=emb_dim))
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     hip = LSENeRFModel(cfg, aabb, num_train_data)
     if param_scale != 1.0:   # larger table values make the hash contribution visible above fp32 noise
@@ -140,7 +140,7 @@ def make_model_pair(grid_levels=4, grid_resolution=128, seed=96, occupied_frac=0
     n_emb = hip.field.embedding_appearance.embedding.weight.shape[0]
     f = FieldOracle("tcnn", num_levels=num_levels, hidden_dim=hidden, hidden_dim_color=hidden,
                     log2_hashmap_size=log2_hashmap_size, num_embeddings=n_emb, contraction=contraction, aabb=aabb,
-                    seed=seed)
+                    seed=seed, appearance_embedding_dim=emb_dim)
     sync_params_to_oracle(hip, f)
     orc = ModelOracle(f, grid_resolution=grid_resolution, grid_levels=grid_levels, alpha_thre=alpha_thre,
                       cone_angle=cone_angle)
