@@ -11,8 +11,12 @@ headline workload (`m_march_inside_box`: origins inside the box, exactly 1024 sa
 SURVEY 8d's M-packed, the reference's default configuration, and the reference's real 3-bundle step compositions.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); per-GPU work is fixed (weak
-scaling): each rank renders its own 4096 rays and the gradient is all-reduced once per step.
+N > 1: one rank per GPU over RCCL; per-GPU work is fixed (weak scaling): each rank renders its own 4096 rays and the gradient
+is all-reduced once per step.  Under a launcher (``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``:
+WORLD_SIZE is set) this process IS a rank.  Started bare (``python bench.py --gpus N``, no WORLD_SIZE) it is the PARENT: before
+anything touches the GPU -- torch is not even imported -- it starts N fresh rank processes (lsenerf_amd/launch.py; what
+R:train.py:171-234 does with mp.spawn), relays rank 0's JSON line and exits with the ranks' code.  A rank whose WORLD_SIZE
+differs from --gpus is an error, never a silent N = 1 measurement.
 """
 from __future__ import annotations
 
@@ -22,10 +26,34 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _load_launcher():
+    """lsenerf_amd/launch.py loaded by PATH: importing the package would import torch, and the launching parent must not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lse_launch", os.path.join(ROOT, "lsenerf_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _gpus_requested(argv) -> int:
+    """--gpus N / --gpus=N from the command line, before argparse (and torch) come into play."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+# `python bench.py --gpus N` without a launcher: this process is the PARENT of N ranks and stays clear of torch and the GPU
+IS_LAUNCHING_PARENT = __name__ == "__main__" and _load_launcher().needs_launch(_gpus_requested(sys.argv[1:]))
+if not IS_LAUNCHING_PARENT:
+    import torch
 
 RAYS_PER_GPU = 4096
 SAMPLES_PER_RAY = 1024
@@ -163,10 +191,7 @@ def _restore(model, opt, snap):
         opt.step_count = snap[3]
         est.occs.copy_(snap[4]); est.binaries.copy_(snap[5])
     est._bump_grid_version()
-    est._occ_mean_host = None
-    if "_occ_mean_dev" in est.__dict__:
-        est.__dict__["_occ_mean_dev_version"] = None
-        est._occ_mean_device()
+    est._invalidate_occ_mean()
 
 
 def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None, prefetch=False):
@@ -509,7 +534,14 @@ def main():
     ap.add_argument("--no-atomic-floor", action="store_true",
                     help="skip roofline.atomic (its request count sorts 16 x 8 x N indices with torch kernels AFTER the timed region: "
                          "left out of rocprofv3 passes so that the kernel statistics hold the step's kernels only)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are terminated after this many seconds")
     args = ap.parse_args()
+
+    # -- self-launch (R:train.py:171-234): `python bench.py --gpus N` without a launcher starts its own N ranks ------------------
+    if IS_LAUNCHING_PARENT:
+        sys.exit(_load_launcher().launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                               timeout=args.launch_timeout,
+                                               stdout_filter=lambda line: line.lstrip().startswith("{")))
 
     from lsenerf_amd import _lib, ops, dist as ldist
     from lsenerf_amd.optim import FlatAdam, FlatParams
@@ -517,8 +549,13 @@ def main():
 
     # RCCL ("nccl") over xGMI on a real multi-GPU node; LSE_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse
     # the multi-rank control path on a single-GPU box (the collective then stages through the host).
-    rank, world, local = ldist.init_from_env(os.environ.get("LSE_BENCH_BACKEND", "nccl"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    backend = os.environ.get("LSE_BENCH_BACKEND", "nccl")
+    rank, world, local = ldist.init_from_env(backend)
+    if world != args.gpus:      # (a bare `--gpus N` never gets here: it became the launching parent above)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    ranks_seen = tdist.get_world_size() if tdist.is_initialized() else 1
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {ranks_seen} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
@@ -595,12 +632,18 @@ def main():
         dom_ms = dom_ms_all[dom]
         achieved = HASH_BYTES_PER_SAMPLE * n_samples / (dom_ms * 1e-3) / 1e9
         b_step = n_samples * BYTES_PER_SAMPLE_STEP + 8 * 4 * flat.numel
-        traffic, sq_busy = None, None
-        try:   # committed PMC summary of the same kernels (bench.py cannot run rocprofv3 on itself); see profiles/pmc_traffic.json
+        traffic, sq_busy, stale = None, None, None
+        try:   # committed PMC summary of the same kernels (bench.py cannot run rocprofv3 on itself); see profiles/pmc_traffic.json.
+            # Each group of counters is stamped with a digest of the kernel sources it was measured on (lsenerf_amd/provenance.py);
+            # numbers from other sources than this tree's are NOT reported: null fields + "traffic_stale": true
+            from lsenerf_amd import provenance
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            traffic = pmc.get(dom, {}).get("bytes")
-            sq_busy = pmc.get("matrix_core_busy")
+            stale = {"hash": not provenance.counters_current(pmc, "hash"), "mlp": not provenance.counters_current(pmc, "mlp")}
+            if not stale["hash"]:
+                traffic = pmc.get(dom, {}).get("bytes")
+            if not stale["mlp"]:
+                sq_busy = pmc.get("matrix_core_busy")
         except OSError:
             pass
         atomic = None
@@ -623,7 +666,8 @@ def main():
                               "more (cache collisions; profiles/r03_hash_bwd_memory_side_requests.txt)"}
         line = {
             "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "ranks_seen": ranks_seen, "backend": (tdist.get_backend() if tdist.is_initialized() else None),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "M-march (SURVEY 8d, exact): LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, "
                                    "SH4, 32-d appearance embedding); 4096 rays/GPU from the radius-1.5 sphere aimed into "
@@ -634,6 +678,7 @@ def main():
                        "parallelism": f"dp{world}", "grad_exchange": mode},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                         "traffic_stale": None if stale is None else stale["hash"],
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": HASH_BYTES_PER_SAMPLE * n_samples,
                          "atomic": atomic},
             "step_roofline": {"algorithmic_bytes_per_step": b_step,
@@ -648,7 +693,7 @@ def main():
                 "executed_bf16_flop_per_sample": MLP_BF16_FLOP_PER_SAMPLE,
                 "executed_bf16_TFLOPs": MLP_BF16_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 1e12, "bf16_peak_TFLOPs": 2500.0,
                 "executed_bf16_frac": MLP_BF16_FLOP_PER_SAMPLE * n_samples / (1e-3 * t_ms) / 2.5e15,
-                "matrix_core_busy": sq_busy})(
+                "matrix_core_busy": sq_busy, "matrix_core_busy_stale": None if stale is None else stale["mlp"]})(
                     kern_ms.get("lse_mlp_fwd", 0) + kern_ms.get("lse_mlp_bwd", 0) + kern_ms.get("lse_mlp_wgrad", 0) + 1e-9),
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
             "kernel_ms_note": "per C-ABI entry point, from a separate instrumented pass of %d steps (event pairs around every "

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSE_ABI_VERSION 3
+#define LSE_ABI_VERSION 4
 
 #define LSE_OK 0
 #define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
@@ -391,9 +391,16 @@ int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, c
 int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream);
 /* The same with the step-dependent scalars in device memory: hyper[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)}.  A launch
- * captured into a HIP graph cannot carry new scalar arguments; the host refreshes these three floats before every replay. */
+ * captured into a HIP graph cannot carry new scalar arguments; lse_adam_schedule_dev (captured in front of it) derives them. */
 int lse_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *hyper,
                       float beta1, float beta2, float eps, float grad_scale, lse_stream_t stream);
+/* Device-side optimizer clock (ABI 4): *step (optimizer steps taken so far, int64 in device memory) is advanced by one and
+ * hyper[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} of the NEW step is written, with nerfstudio's
+ * ExponentialDecayScheduler lr = lr_init * (lr_final / lr_init)^(min(steps taken / max_steps, 1)) (max_steps <= 0 or
+ * lr_final <= 0: constant lr_init; R:lse_nerf/lse_config.py:29-38).  Replaces the per-step host -> device copy of the three
+ * scalars: a replayed graph depends on nothing the host writes, however far the host runs ahead. */
+int lse_adam_schedule_dev(int64_t *step, float *hyper, double lr_init, double lr_final, int64_t max_steps, double beta1,
+                          double beta2, lse_stream_t stream);
 
 #ifdef __cplusplus
 }

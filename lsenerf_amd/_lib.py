@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSE_HIP_LIB", os.path.join(_HERE, "liblse_hip.so"))   # override: A/B builds of the same ABI
@@ -16,7 +16,7 @@ LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
 LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
 LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
-LSE_ABI_VERSION = 3
+LSE_ABI_VERSION = 4
 
 
 class GridDesc(Structure):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],
     "lse_adam_step_dev": [P, P, P, P, I64, P, F32, F32, F32, F32, P],
+    "lse_adam_schedule_dev": [P, P, c_double, c_double, I64, c_double, c_double, P],
 }
 
 _lib = None

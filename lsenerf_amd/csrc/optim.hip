@@ -49,6 +49,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+// One thread: advance the device-side step counter and derive the step's scalars from it, in double like the host does for
+// lse_adam_step.  Captured into a HIP graph in front of adam_kernel, a replayed step needs nothing from the host: there is no
+// staging buffer a host that runs ahead of the device could overwrite before the queued copy has executed.
+__global__ void adam_schedule_kernel(int64_t *__restrict__ step, float *__restrict__ hyper, double lr_init, double lr_final,
+                                     int64_t max_steps, double b1, double b2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t done = *step;                 // optimizer steps taken so far: the learning rate is the one of step `done`
+    const int64_t t = done + 1;
+    *step = t;
+    double lr = lr_init;
+    if (max_steps > 0 && lr_final > 0.0) {      // nerfstudio ExponentialDecayScheduler without warm-up
+        const double f = fmin(fmax((double)done / (double)max_steps, 0.0), 1.0);
+        lr = exp(log(lr_init) * (1.0 - f) + log(lr_final) * f);
+    }
+    hyper[0] = (float)lr;
+    hyper[1] = (float)(1.0 - pow(b1, (double)t));
+    hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, (double)t)));
+}
+
 // occs[id] = max(occs[id]*ema, occ_new) with duplicate ids resolved as the maximum over the duplicates:
 //   pass 1: ws[i] = max(occs[id_i]*ema, occ_i)      (reads only)
 //   pass 2: occs[id_i] = 0                           (benign same-value race)
@@ -111,6 +131,17 @@ extern "C" int lse_adam_step_dev(float *params, const float *grads, float *exp_a
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
                        n, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, hyper);
     return lse::check_launch("lse_adam_step_dev");
+}
+
+extern "C" int lse_adam_schedule_dev(int64_t *step, float *hyper, double lr_init, double lr_final, int64_t max_steps,
+                                     double beta1, double beta2, lse_stream_t stream)
+{
+    LSE_REQUIRE(step && hyper, "lse_adam_schedule_dev: null pointer");
+    LSE_REQUIRE(lr_init > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0,
+                "lse_adam_schedule_dev: need lr_init > 0 and betas in [0, 1)");
+    hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(64), 0, lse::as_stream(stream), step, hyper, lr_init, lr_final,
+                       max_steps, beta1, beta2);
+    return lse::check_launch("lse_adam_schedule_dev");
 }
 
 extern "C" int lse_occ_update_cells(float *occs, const int64_t *cell_ids, const float *occ_new, int64_t n,

@@ -34,7 +34,7 @@ struct TraverseArgs {
     int32_t *ray_indices;
     float *t_starts, *t_ends;
     int64_t cap;          // MODE 2: samples of ray r go to slots [r*cap, (r+1)*cap)
-    int32_t *overflow;    // MODE 2: set when a ray produced more than cap samples (never, by the host's bound)
+    int32_t *overflow;    // MODE 2: OR-ed (never cleared) when a ray produced more than cap samples (never, by the host's bound)
     int vec_march;        // constant step: march 64 steps of a cell at once (march_cell_vec); 0 = published serial loop only
     int fma_setup;        // option "traverse_fma": the a*b+c sites of the traversal setup as fused multiply-adds (nvcc's default
                           // contraction of grid.cu); 0 = every product and sum rounded separately (default, == oracle build 1)
@@ -373,8 +373,12 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
             __syncthreads();   // the next batch overwrites the LDS slots
         }
     }
-    if (MODE != 1 && lane == 0) a.chunk_cnts[tid] = (int64_t)n_samples;
-    if (MODE == 2 && lane == 0 && n_samples > cap32) atomicOr(a.overflow, 1);
+    // MODE 2: the count handed on is CLAMPED to the capacity -- pack_info / lse_compact_ray_slots then never read a neighbour's
+    // slots nor write past the R*cap packed arrays: a violated bound truncates the ray and raises the sticky flag (bit 0; bit 1:
+    // the direction of such a ray was shorter than 1, which is what the host's bound assumes)
+    if (MODE != 1 && lane == 0) a.chunk_cnts[tid] = (int64_t)(MODE == 2 && n_samples > cap32 ? cap32 : n_samples);
+    if (MODE == 2 && lane == 0 && n_samples > cap32)
+        atomicOr(a.overflow, 1 | ((d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 0.998f ? 2 : 0));
 }
 
 // nerfstudio's VolumetricSampler inserts ONE fake sample (ray 0, t_start = t_end = 1) when no ray produced any, so that nothing

@@ -300,11 +300,10 @@ def sync_grid(estimator, src: int = 0) -> None:
     dist.broadcast(b8, src=src)
     if hasattr(estimator, "_bump_grid_version"):
         estimator._bump_grid_version()
-    if hasattr(estimator, "_occ_mean_host"):
+    if hasattr(estimator, "_invalidate_occ_mean"):       # host / device copies of occs.mean() (the cap of the alpha threshold)
+        estimator._invalidate_occ_mean()
+    elif hasattr(estimator, "_occ_mean_host"):
         estimator._occ_mean_host = None
-    if "_occ_mean_dev" in getattr(estimator, "__dict__", {}):      # device-side copy of occs.mean() (count-free sampler path)
-        estimator.__dict__["_occ_mean_dev_version"] = None
-        estimator._occ_mean_device()
 
 
 def attach_grid_sync(estimator, src: int = 0):

@@ -12,7 +12,8 @@ which is the capturing stream) and replayed with one call per step.
 What varies from step to step enters through device memory at fixed addresses:
   * the rays and targets of the step   -> copied into the static input tensors before the replay;
   * the stratified jitter              -> ``torch.rand`` inside the graph (graph-safe Philox offsets), or a static input;
-  * the learning rate / bias corrections -> three floats staged by ``FlatAdam.prepare_step`` (lse_adam_step_dev);
+  * the learning rate / bias corrections -> derived ON THE DEVICE from a step counter the graph itself advances
+    (lse_adam_schedule_dev in front of lse_adam_step_dev): no per-step host -> device copy that a host running ahead could race;
   * the occupancy grid and ``occs.mean()`` (the cap of the alpha threshold) -> refreshed in place, outside the graph, by
     ``LSENeRFModel.update_occupancy_grid`` between replays (lse_visibility_mask_cap reads the mean on the device).
 Everything else (step size, cone angle, shapes, capacities) is constant for a given model and batch composition.
@@ -73,7 +74,7 @@ def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool
     """Capture ``body()`` -- a zero-argument callable that runs one step on tensors at fixed addresses and synchronises with
     nothing -- into a HIP graph.  Warm-up runs on a side stream as torch.cuda.graph requires (allocator pools, lazy
     initialisation); the optimizer state those eager runs change is saved and restored, so capturing trains nothing.
-    Returns (graph, overflow flags of the captured marcher calls)."""
+    Returns the graph."""
     dev = opt.flat.data.device if opt is not None else estimator.occs.device
     estimator._occ_mean_device()                          # allocate / refresh the device-side alpha cap before the capture
     saved = (opt.flat.data.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count) if opt is not None else None
@@ -91,16 +92,13 @@ def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool
         opt.prepare_step()
     with torch.cuda.graph(graph, pool=pool):
         body()
-    # the capture records launches, it does not run them: the overflow flag of a captured marcher call means something only
-    # after a replay -- it is handed to the caller instead of staying in the estimator's list
-    flags = estimator.__dict__.get("_deferred_flags", [])
-    captured_flags = list(flags)
-    del flags[:]
+    # (the captured marcher calls OR into the estimator's sticky overflow accumulator at every replay, like the eager ones:
+    #  LSEOccGridEstimator._overflow_flag -- read at the occupancy refresh and by check_overflow())
     if opt is not None:
         with torch.no_grad():
             opt.flat.data.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
         opt.step_count = saved[3]
-    return graph, captured_flags
+    return graph
 
 
 class GraphedTrainStep:
@@ -143,7 +141,7 @@ class GraphedTrainStep:
         self.prefetch_fork = prefetch_fork
         self.replays = 0
         if not self.prefetch:
-            self.graph, self._overflow_flags = capture_body(self._body, opt, model.occupancy_grid, warmup)
+            self.graph = capture_body(self._body, opt, model.occupancy_grid, warmup)
             return
         # -- marcher of the next step on a side stream: two graphs alternate between two sample buffers
         self.next_col, self.next_prev, self.next_nxt = (_static_like(b, False) for b in (col, prev, nxt))
@@ -151,15 +149,12 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pm = [model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter) for _ in range(2)]
         est = model.occupancy_grid
-        del est.__dict__.get("_deferred_flags", [])[-2:]          # these two buffers' flags are checked by check_overflow()
         self._side = torch.cuda.Stream(device=dev)
         self._graphs, self._losses_of, self._outputs_of, self._ray_grads_of = [], [], [], []
-        self._overflow_flags = [pm.overflow for pm in self._pm]
         for x in (0, 1):
-            g, flags = capture_body(lambda x=x: self._body_prefetch(x), opt, est, warmup if x == 0 else 1,
-                                    pool=self._graphs[0].pool() if self._graphs else None)
+            g = capture_body(lambda x=x: self._body_prefetch(x), opt, est, warmup if x == 0 else 1,
+                             pool=self._graphs[0].pool() if self._graphs else None)
             self._graphs.append(g)
-            self._overflow_flags += flags
             self._losses_of.append(self.losses)
             self._outputs_of.append(self.outputs)
             self._ray_grads_of.append(self._collect_ray_grads())
@@ -293,9 +288,9 @@ class GraphedTrainStep:
         return self.losses
 
     def check_overflow(self) -> None:
-        """One host synchronisation: raises if a replayed marcher call exceeded the proven per-ray capacity (never expected)."""
-        if self.replays and self._overflow_flags and bool(torch.stack([f.reshape(()) for f in self._overflow_flags]).any().item()):
-            raise RuntimeError("captured step: a ray produced more samples than LSEOccGridEstimator._cap_per_ray allows")
+        """One host synchronisation: raises if a marcher call -- replayed or eager -- exceeded the per-ray capacity (the estimator's
+        sticky accumulator; ``LSENeRFModel.update_occupancy_grid`` makes the same check at every refresh)."""
+        self.model.occupancy_grid.check_deferred_overflow()
 
     def close(self):
         self.model.deferred_counts, self.model.deferred_max_slots = self._deferred_before

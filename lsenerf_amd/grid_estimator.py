@@ -36,7 +36,7 @@ class Premarched(NamedTuple):
     t_ends: Tensor            # [R * cap]
     packed_info: Tensor       # int64 [R, 2]
     n_dev: Tensor             # int64 [1]: valid leading entries
-    overflow: Tensor          # int32 [1]: != 0 if a ray exceeded the proven capacity (never expected; checked lazily)
+    overflow: Tensor          # int32 [1]: the estimator's sticky accumulator (LSEOccGridEstimator._overflow_flag)
     grid_version: int         # LSEOccGridEstimator.grid_version when the marcher was launched
     n_rays: int
 
@@ -115,12 +115,44 @@ class LSEOccGridEstimator(nn.Module):
             self.__dict__["_occ_mean_dev_version"] = self.occs._version
         return buf
 
+    def _overflow_flag(self) -> Tensor:
+        """The ONE sticky overflow accumulator of this estimator (int32 [1] on the grid's device): every count-free marcher call --
+        eager, captured into a HIP graph, or running ahead on a side stream -- ORs into it and nothing clears it but
+        ``check_deferred_overflow``, so no call's flag can be dropped unread however long the host waits to look."""
+        buf = self.__dict__.get("_overflow_acc")
+        if buf is None or buf.device != self.occs.device:
+            buf = self.__dict__["_overflow_acc"] = torch.zeros(1, dtype=torch.int32, device=self.occs.device)
+        return buf
+
+    def _invalidate_occ_mean(self) -> None:
+        """Call after ANY write to ``occs`` (refresh, mark_all_occupied, dist.sync_grid, load_state_dict).  The HIP kernels write
+        `occs` through its raw pointer (no tensor version bump), and a captured step reads the device-side mean at its fixed
+        address: the host copy is dropped and the device copy recomputed now, in place."""
+        self._occ_mean_host = None
+        if "_occ_mean_dev" in self.__dict__:
+            self.__dict__["_occ_mean_dev_version"] = None
+            self._occ_mean_device()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # a checkpoint's `occs` / `binaries` replace the grid: samples marched ahead are stale, so is min(alpha_thre, occs.mean())
+        super()._load_from_state_dict(*args, **kwargs)
+        self._bump_grid_version()
+        self._invalidate_occ_mean()
+
     def check_deferred_overflow(self) -> None:
-        """Deferred sampling never reads the marcher's slot-overflow flag on the critical path (the capacity is a proven
-        bound); this reads the flags of the calls made so far -- one host synchronisation -- and raises if one is set."""
-        flags, self._deferred_flags = getattr(self, "_deferred_flags", []), []
-        if flags and bool(torch.stack([f.reshape(()) for f in flags]).any().item()):
-            raise RuntimeError("deferred sampling: a ray produced more samples than LSEOccGridEstimator._cap_per_ray allows")
+        """Deferred sampling never reads the marcher's slot-overflow flag on the critical path (the capacity is a proven bound for
+        unit-length directions, and a violated bound truncates the ray instead of leaving its slots); this reads the sticky
+        accumulator of all calls made so far -- one host synchronisation -- and raises if it is set.  The training path calls it
+        at every occupancy refresh (``LSENeRFModel.update_occupancy_grid``: that step synchronises anyway)."""
+        buf = self.__dict__.get("_overflow_acc")
+        if buf is None:
+            return
+        bits = int(buf.item())
+        if bits:
+            buf.zero_()
+            raise RuntimeError("deferred sampling: a ray produced more samples than LSEOccGridEstimator._cap_per_ray allows; its samples "
+                               "were truncated to the capacity" + (" (that ray's direction is shorter than 1: the bound assumes "
+                               "normalised directions -- normalise them or use the synchronising sampler)" if bits & 2 else ""))
 
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
@@ -210,12 +242,7 @@ class LSEOccGridEstimator(nn.Module):
         cap = self._cap_per_ray(near_plane, far_plane, render_step_size, cone_angle)
         res = ops.traverse_grids_deferred(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
-            render_step_size, cone_angle, cap, out=None if out is None else tuple(out)[:6])
-        if out is None:       # (the owner of reused buffers checks their flag itself: Premarched.overflow)
-            flags = self.__dict__.setdefault("_deferred_flags", [])
-            flags.append(res[5])
-            if len(flags) > 4096:
-                del flags[:2048]
+            render_step_size, cone_angle, cap, out=None if out is None else tuple(out)[:6], overflow=self._overflow_flag())
         return Premarched(*res, self.grid_version, rays_o.shape[0])
 
     def _sampling_deferred(self, rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
@@ -322,12 +349,7 @@ class LSEOccGridEstimator(nn.Module):
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre).reshape(1).contiguous()
         ops.occ_binarize(self.occs, thre, self._binaries_u8().view(-1))
         self._bump_grid_version()
-        self._occ_mean_host = None
-        # the HIP kernels write `occs` through its raw pointer (no tensor version bump): refresh the device-side mean explicitly,
-        # now and in place -- a captured step reads that buffer at its fixed address
-        if "_occ_mean_dev" in self.__dict__:
-            self.__dict__["_occ_mean_dev_version"] = None
-            self._occ_mean_device()
+        self._invalidate_occ_mean()
         hook = getattr(self, "after_update_hook", None)      # data parallel: dist.attach_grid_sync
         if hook is not None:
             hook()
@@ -337,4 +359,4 @@ class LSEOccGridEstimator(nn.Module):
         self.occs.fill_(value)
         self.binaries.fill_(True)
         self._bump_grid_version()
-        self._occ_mean_host = None
+        self._invalidate_occ_mean()

@@ -390,7 +390,12 @@ class LSENeRFModel(nn.Module):
             self.rgb_to_one = ToGrayGT()
 
     def update_occupancy_grid(self, step: int) -> None:
-        """The body of NGPModel's training callback: refresh the occupancy grid from ``density * render_step_size``."""
+        """The body of NGPModel's training callback: refresh the occupancy grid from ``density * render_step_size``.
+        On the steps that refresh (every 16th; they synchronise with the device anyway) the count-free sampler's sticky
+        overflow accumulator is read first: a violated per-ray capacity (truncated rays) raises here, in the eager and in the
+        graph-replayed training step alike, at most 16 steps after it happened."""
+        if self.training and step % 16 == 0:
+            self.occupancy_grid.check_deferred_overflow()
         self.occupancy_grid.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * self.config.render_step_size)
 
@@ -518,15 +523,22 @@ class LSENeRFModel(nn.Module):
     def _plan(self) -> Dict[str, object]:
         cfg = self.config
         mode = cfg.map_mode if (cfg.use_mapping or cfg.map_mode == "rgb_evs") else None
+        # a map_mode that names none of the three routes -- the reference's own default spelling "ev_rgb" is one
+        # (R:lse_nerf/lsenerf.py:80) -- falls through every branch of the reference's get_outputs (:335-363): no mapper runs and
+        # no "ev_out" exists, so an rgb-only batch trains and an event batch fails with the reference's KeyError('ev_out') in
+        # get_loss_dict (:432-433).  Same here: such a plan takes the torch route (``unrouted``), never the fused epilogue.
+        unrouted = mode is not None and mode not in ("co_map", "evs_rgb", "rgb_evs")
+        if unrouted:
+            mode = None
         one_dim = getattr(self, "rgb_to_one", None) if cfg.ev_one_dim else None
         if cfg.use_mapping:        # the event loss reads "ev_out"
-            ev_mapper = {"co_map": self.evs_mapper, "evs_rgb": None, "rgb_evs": getattr(self, "rgb_mapper", None)}[cfg.map_mode]
+            ev_mapper = {"co_map": self.evs_mapper, "evs_rgb": None, "rgb_evs": getattr(self, "rgb_mapper", None)}.get(cfg.map_mode)
             ev_one_dim = one_dim
         else:                      # ... otherwise the routed "rgb"
             ev_mapper, ev_one_dim = None, None
         return {"mode": mode, "rgb_mapper": getattr(self, "rgb_mapper", None) if mode in ("evs_rgb", "co_map") else None,
                 "ev_key": "ev_out" if cfg.use_mapping else "rgb", "ev_mapper": ev_mapper, "ev_one_dim": ev_one_dim,
-                "deblur_group": 4 if cfg.rgb_loss_type == "deblur" else 1}
+                "deblur_group": 4 if cfg.rgb_loss_type == "deblur" else 1, "unrouted": unrouted}
 
     def get_outputs(self, ray_bundle: RayBundle, ev_out=False, jitter: Optional[Tensor] = None, **kwargs):
         return self.route_outputs(self.exec_get_outputs(ray_bundle, jitter=jitter), ray_bundle, ev_out=ev_out, **kwargs)
@@ -659,7 +671,7 @@ class LSENeRFModel(nn.Module):
         cfg, plan = self.config, self._plan()
         kinds = {IdentityMapper: _lib.LSE_MAP_IDENTITY, GT_Mapper: _lib.LSE_MAP_GT, Powpow: _lib.LSE_MAP_POWPOW,
                  type(None): _lib.LSE_MAP_IDENTITY}
-        if cfg.event_loss_type.lower() != "log_loss" or type(plan["rgb_mapper"]) not in kinds \
+        if plan["unrouted"] or cfg.event_loss_type.lower() != "log_loss" or type(plan["rgb_mapper"]) not in kinds \
                 or type(plan["ev_mapper"]) not in kinds or (plan["ev_key"] == "rgb" and plan["deblur_group"] > 1):
             return None
         od = plan["ev_one_dim"]

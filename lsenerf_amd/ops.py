@@ -202,12 +202,16 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
 
 @torch.no_grad()
 def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
-                            cap: int, out=None):
+                            cap: int, out=None, overflow=None):
     """``traverse_grids`` without the host read-back of the sample count.  ``cap`` is a PROVEN upper bound of the samples of
     one ray (LSEOccGridEstimator._cap_per_ray); the packed outputs have room for ``R * cap`` samples and the actual count stays
     on the device.  Returns (ray_indices int32 [C], t_starts [C], t_ends [C], packed_info int64 [R,2], n_dev int64 [1],
     overflow int32 [1]) with C = R * cap; entries at and beyond n_dev[0] are never written nor read by the kernels that are
-    handed ``n_dev``.  ``overflow`` != 0 would mean the bound was violated (checked lazily by the caller, never expected).
+    handed ``n_dev``.
+    ``overflow``: int32 [1] on the device that the marcher ORs into and NEVER clears -- a sticky accumulator the caller owns
+    (LSEOccGridEstimator keeps one for all its calls, captured ones included, and reads it at the occupancy refresh); a fresh
+    zero is allocated when absent.  Bit 0: a ray exceeded ``cap`` (its samples were truncated to ``cap``: nothing is read or
+    written out of bounds); bit 1: such a ray's direction was shorter than 1.
     ``out``: a previous result of this function for the same R and cap, written into instead of allocating (a marcher that runs
     ahead of its step on a side stream fills buffers at addresses the consumer already knows: lsenerf_amd.graph)."""
     R = rays_o.shape[0]
@@ -218,21 +222,23 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
         raise _lib.LseHipError(f"deferred sampling: {R} rays x {cap} slots exceed the slot budget ({MAX_SLOT_ELEMS})")
     cnts = torch.empty(R, dtype=torch.int64, device=dev)
     if out is not None:
-        ri, ts, te, packed, n_dev_o, flag_o = out
-        if not (ri.shape == ts.shape == te.shape == (C,) and packed.shape == (R, 2) and n_dev_o.data_ptr() + 8 == flag_o.data_ptr()):
+        ri, ts, te, packed, total, flag_o = out
+        if not (ri.shape == ts.shape == te.shape == (C,) and packed.shape == (R, 2) and total.shape == (1,)):
             raise _lib.LseHipError("traverse_grids_deferred: `out` is not a result of this function for the same rays x capacity")
-        total = torch.as_strided(n_dev_o, (2,), (1,))      # [count, overflow flag]: the pair the first call allocated
-        total.zero_()
+        if overflow is None:
+            overflow = flag_o
     else:
         packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
-        total = torch.zeros(2, dtype=torch.int64, device=dev)
+        total = torch.empty(1, dtype=torch.int64, device=dev)       # written (not accumulated) by lse_pack_info_from_counts
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    flag = _chk(overflow, torch.int32, "overflow")
     ts_slots = torch.empty(C, dtype=torch.float32, device=dev)
     te_slots = torch.empty(C, dtype=torch.float32, device=dev)
-    flag = total[1:].view(torch.int32)
     _lib.call("lse_traverse_grids_slots", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), R, _chk(binaries, torch.uint8, "binaries"),
               _f32(aabbs, "aabbs"), L, rx, ry, rz, _f32(near_planes, "near_planes"), _f32(far_planes, "far_planes"),
               float(step_size), float(cone_angle), cap, ctypes.c_void_p(cnts.data_ptr()), ctypes.c_void_p(ts_slots.data_ptr()),
-              ctypes.c_void_p(te_slots.data_ptr()), ctypes.c_void_p(flag.data_ptr()), _stream())
+              ctypes.c_void_p(te_slots.data_ptr()), flag, _stream())
     _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
     if out is None:
@@ -242,7 +248,7 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
     _lib.call("lse_compact_ray_slots", ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()), cap,
               ctypes.c_void_p(packed.data_ptr()), R, ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()),
               ctypes.c_void_p(te.data_ptr()), _stream())
-    return ri, ts, te, packed, total[0:1], flag[0:1]
+    return ri, ts, te, packed, total, overflow
 
 
 @torch.no_grad()
@@ -964,6 +970,14 @@ def adam_step_dev(params, grads, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, 
     _lib.call("lse_adam_step_dev", _f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"),
               _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), _f32(hyper, "hyper"), float(beta1), float(beta2), float(eps),
               float(grad_scale), _stream())
+
+
+@torch.no_grad()
+def adam_schedule_dev(step_dev, hyper, lr_init: float, lr_final: Optional[float], max_steps: Optional[int], beta1, beta2):
+    """Advance the device-side optimizer step counter (int64 [1]) and write (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) of the new
+    step into ``hyper`` (float32 [3]) -- lse_adam_schedule_dev; capturable, reads nothing from the host."""
+    _lib.call("lse_adam_schedule_dev", _chk(step_dev, torch.int64, "step_dev"), _f32(hyper, "hyper"), float(lr_init),
+              float(lr_final) if lr_final else 0.0, int(max_steps) if max_steps else 0, float(beta1), float(beta2), _stream())
 
 
 @torch.no_grad()

@@ -76,23 +76,35 @@ class FlatAdam:
                       self.eps, self.step_count, grad_scale)
 
     # -- captured steps: the launch inside a HIP graph cannot carry this step's scalars, so they live in device memory ----------
+    # The optimizer clock is ON THE DEVICE: an int64 step counter that `lse_adam_schedule_dev` -- captured in front of the Adam
+    # kernel -- advances and turns into (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)).  A replay therefore reads nothing the host writes
+    # per step.  (Until round 3 the host staged the three floats in ONE pinned buffer and queued an asynchronous copy per step: a
+    # host that runs ahead of the device -- which is the point of replaying a graph -- overwrote the buffer before the queued copy
+    # of an earlier step had executed, so early steps could take a later step's bias corrections.)
+    def _device_clock(self):
+        if not hasattr(self, "_hyper_dev"):
+            dev = self.flat.data.device
+            self._hyper_dev = torch.zeros(3, dtype=torch.float32, device=dev)
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._step_dev_expected = None
+        return self._step_dev, self._hyper_dev
+
     def prepare_step(self) -> None:
-        """Advance the step count and stage (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) of the NEW step in device memory (an
-        asynchronous 12-byte copy on the current stream).  Call before replaying a graph that contains ``step_staged``."""
-        import math
-        lr = self.current_lr()
+        """Host bookkeeping of one captured step: makes sure the device-side step counter equals ``step_count`` (a stream-ordered
+        fill with the value in the launch arguments, only after the host-side count was changed from outside: construction,
+        load_state_dict, a restored snapshot) and advances the host's mirror.  Call before replaying -- or capturing -- a graph
+        that contains ``step_staged``."""
+        step_dev, _ = self._device_clock()
+        if self._step_dev_expected != self.step_count:
+            step_dev.fill_(int(self.step_count))
         self.step_count += 1
-        if not hasattr(self, "_hyper_host"):
-            self._hyper_host = torch.empty(3, dtype=torch.float32).pin_memory()
-            self._hyper_dev = torch.empty(3, dtype=torch.float32, device=self.flat.data.device)
-        self._hyper_host[0] = lr
-        self._hyper_host[1] = 1.0 - self.betas[0] ** self.step_count
-        self._hyper_host[2] = 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        self._step_dev_expected = self.step_count
 
     def step_staged(self, grad_scale: float = 1.0) -> None:
-        """The Adam update with the scalars ``prepare_step`` staged (lse_adam_step_dev): capturable."""
-        ops.adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self._hyper_dev, self.betas[0],
+        """Device clock tick + the Adam update with the scalars it derived (lse_adam_schedule_dev, lse_adam_step_dev): capturable."""
+        step_dev, hyper = self._device_clock()
+        ops.adam_schedule_dev(step_dev, hyper, self.lr_init, self.lr_final, self.max_steps, self.betas[0], self.betas[1])
+        ops.adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, hyper, self.betas[0],
                           self.betas[1], self.eps, grad_scale)
 
     # -- resume (nerfstudio saves ``optimizers: {"fields": optimizer.state_dict()}``, R:lse_nerf/lse_trainer.py:85-122) ------

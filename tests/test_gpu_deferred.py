@@ -186,3 +186,57 @@ def test_samples_marched_ahead_of_the_step_are_the_steps_own_samples():
     m.update_occupancy_grid(5)            # not a refresh step: nothing changes
     assert est.grid_version == v0 + 2
     est.check_deferred_overflow()
+
+
+def test_a_violated_capacity_truncates_rays_in_bounds_and_is_reported_at_the_next_refresh():
+    """The count-free sampler's capacity is a proven bound for unit-length directions.  When it is violated anyway (here: forced
+    to 24 slots per ray; and once through directions of length 0.25) the marcher truncates the ray to its capacity -- the count it
+    hands on never exceeds the slots, nothing is read from a neighbour's slots nor written past the packed arrays -- and ORs into
+    the estimator's sticky accumulator, which the product path reads at the next occupancy refresh
+    (LSENeRFModel.update_occupancy_grid) and which is never dropped unread, however many calls lie in between."""
+    from lsenerf_amd import RayBundle
+    m = _model(cone_angle=0.0, alpha_thre=0.0)
+    m.occupancy_grid.binaries.fill_(True)
+    est = m.occupancy_grid
+    R = 96
+    o, d = random_rays(R, seed=7)
+    o, d = o.cuda(), d.cuda()
+    step = m.config.render_step_size
+    ref = est.sampling(o, d, near_plane=0.05, far_plane=1e3, render_step_size=step, return_packed=True)
+    full_cnt = ref[3][:, 1]
+    assert int(full_cnt.max()) > 100
+    cap = 24
+    est._cap_per_ray = lambda *a, **k: cap
+    ri, ts, te, packed, n_dev = est.sampling(o, d, near_plane=0.05, far_plane=1e3, render_step_size=step, deferred=True)
+    assert ts.shape[0] == R * cap
+    cnt = packed[:, 1]
+    assert torch.equal(cnt, full_cnt.clamp(max=cap))                     # truncated to the capacity, ray by ray
+    n = int(n_dev)
+    assert n == int(cnt.sum()) <= R * cap
+    assert torch.equal(packed[:, 0], torch.cumsum(cnt, 0) - cnt)
+    # the kept samples are the FIRST `cap` samples of each ray of the synchronising path, bit for bit
+    keep = torch.cat([torch.arange(int(s), int(s) + int(c), device="cuda") for s, c in zip(ref[3][:, 0], cnt)])
+    assert torch.equal(ts[:n], ref[1][keep]) and torch.equal(te[:n], ref[2][keep]) and torch.equal(ri[:n], ref[0][keep])
+    # many more calls: the flag must survive them (until round 3 a Python list dropped its oldest 2048 entries unread)
+    del est._cap_per_ray
+    for _ in range(40):
+        est.sampling(o, d, near_plane=0.05, far_plane=1e3, render_step_size=step, deferred=True)
+    m.update_occupancy_grid(3)                                           # not a refresh step: nothing is read
+    with pytest.raises(RuntimeError, match="more samples than"):
+        m.update_occupancy_grid(16)
+    m.update_occupancy_grid(32)                                          # reported once, then clear
+    # directions shorter than 1 stretch the t-range inside the box beyond the bound: truncated, flagged, and named in the message
+    est.sampling(o, d * 0.25, near_plane=0.05, far_plane=1e3, render_step_size=step, deferred=True)
+    with pytest.raises(RuntimeError, match="shorter than 1"):
+        est.check_deferred_overflow()
+    est.check_deferred_overflow()
+    # ... and the whole eager training step on truncated rays runs to completion (no fault) before the refresh reports it
+    est._cap_per_ray = lambda *a, **k: cap
+    rb = RayBundle(origins=o.clone().requires_grad_(True), directions=d.clone().requires_grad_(True),
+                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device="cuda"),
+                   metadata={"appearance_id": torch.zeros(R, dtype=torch.long, device="cuda")})
+    out = m.exec_get_outputs(rb)
+    out["rgb"].sum().backward()
+    assert int(out["num_samples_per_ray"].max()) <= cap and bool(torch.isfinite(out["rgb"]).all())
+    with pytest.raises(RuntimeError, match="more samples than"):
+        m.update_occupancy_grid(48)

@@ -236,3 +236,71 @@ def test_graph_without_the_optimizer_leaves_exchange_and_update_to_the_caller(pr
         assert o_g.step_count == o_e.step_count == it + 1
     step.check_overflow()
     step.close()
+
+
+def test_a_violated_capacity_inside_a_replayed_graph_is_reported_at_the_next_refresh():
+    """The captured marcher ORs into the estimator's sticky overflow accumulator at every replay.  Capture with rays that yield
+    nothing (so that construction sees no overflow), replay with rays that exceed a capacity forced to 24 slots: the replays run
+    to completion on truncated rays and the next occupancy refresh raises."""
+    from lsenerf_amd import RayBundle
+    from lsenerf_amd.graph import GraphedTrainStep
+    (_, m), (_, opt), batch_of = _setup(False)
+    m.occupancy_grid._cap_per_ray = lambda *a, **k: 24
+    (col, prev, nxt), batch, jit = batch_of(50)
+    away = lambda b: RayBundle(origins=b.origins + 50.0, directions=b.directions, camera_indices=b.camera_indices, metadata=b.metadata)
+    step = GraphedTrainStep(m, opt, away(col), away(prev), away(nxt), batch, jitter="input")
+    step(away(col), away(prev), away(nxt), batch, jitter=jit)
+    m.update_occupancy_grid(16)                      # nothing overflowed so far
+    m.occupancy_grid.binaries.fill_(True)
+    m.occupancy_grid._bump_grid_version()
+    for _ in range(3):
+        losses = step(col, prev, nxt, batch, jitter=jit)
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    assert int(step.outputs["col_out"]["num_samples_per_ray"].max()) <= 24
+    with pytest.raises(RuntimeError, match="more samples than"):
+        m.update_occupancy_grid(32)
+    step.check_overflow()                            # reported once
+    step.close()
+
+
+def test_replays_issued_far_ahead_of_the_device_take_their_own_steps_scalars():
+    """The optimizer clock of a captured step is on the device (lse_adam_schedule_dev): 64 replays are issued back to back while
+    the device is still busy with a long kernel queued in front of them -- the host is 64 steps ahead -- and every replay must
+    see ITS step's learning rate and bias corrections.  (A per-step host -> device copy out of one pinned staging buffer, the
+    round-3 scheme, hands early replays the scalars of later steps in exactly this situation.)"""
+    import math
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    p = torch.nn.Parameter(torch.randn(1 << 16, device="cuda"))
+    opt = FlatAdam(FlatParams([p]), lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=40)
+    opt.step_count = 5                               # e.g. resumed from a checkpoint
+    opt.flat.grad.normal_()
+    n = 64
+    log = torch.zeros(n + 8, 3, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.prepare_step(); opt.step_staged()
+    torch.cuda.current_stream().wait_stream(side)
+    opt.step_count = 5
+    graph = torch.cuda.CUDAGraph()
+    opt.prepare_step()
+    with torch.cuda.graph(graph):
+        opt.step_staged()
+        log.index_copy_(0, opt._step_dev - 6, opt._hyper_dev[None])
+    opt.step_count = 5
+    big = torch.randn(8192, 8192, device="cuda")
+    for _ in range(6):                               # ~ tens of milliseconds of device work queued in front of the replays
+        big = big @ big * 1e-4
+    for _ in range(n):
+        opt.prepare_step()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert opt.step_count == 5 + n and int(opt._step_dev) == 5 + n
+    got = log[:n].double().cpu()
+    for i in range(n):
+        t = 6 + i                                    # the step this replay takes; its lr is that of `t - 1` finished steps
+        f = min((t - 1) / 40, 1.0)
+        lr = math.exp(math.log(1e-2) * (1 - f) + math.log(1e-4) * f)
+        want = (lr, 1 - 0.9 ** t, 1 / math.sqrt(1 - 0.999 ** t))
+        for a, b in zip(got[i].tolist(), want):
+            assert abs(a - b) <= 2e-7 * abs(b), (i, got[i].tolist(), want)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
     assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts", "lse_hash_bwd_workspace_bytes"} == set(names)
-    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 3
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 4
 
 
 def test_runtime_options_and_hash_bwd_opts_without_gpu():
@@ -275,3 +275,69 @@ def test_bench_request_floor_counts_the_lines_the_oracle_indexing_touches():
         for s in range(0, n, 64):
             want += np.unique(lines[s:s + 64]).size
     assert bench.hash_bwd_request_floor(x01, meta) == want
+
+
+def test_unknown_map_mode_falls_through_like_the_reference():
+    """The reference's DEFAULT map_mode is the spelling "ev_rgb" (R:lse_nerf/lsenerf.py:80), which names none of the three routes:
+    its get_outputs falls through every branch (:335-363) -- no mapper runs, no "ev_out" is produced -- so with use_mapping an
+    rgb-only batch works and an event batch fails in get_loss_dict with KeyError('ev_out') (:432-433).  Same here, never a
+    KeyError('ev_rgb') from the routing plan, and such a configuration never takes the fused epilogue."""
+    import lsenerf_amd as la
+    m = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="identity", num_levels=4, hidden_dim=32,
+                                              hidden_dim_color=32, grid_levels=1, grid_resolution=8), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4).train()
+    assert m.config.map_mode == "ev_rgb"
+    plan = m._plan()
+    assert plan["mode"] is None and plan["unrouted"] and plan["ev_mapper"] is None and plan["ev_key"] == "ev_out"
+    assert m._epilogue_desc() is None
+    raw = {"rgb": torch.rand(6, 3), "accumulation": torch.rand(6, 1), "depth": torch.rand(6, 1)}
+    routed = m.route_outputs(dict(raw), None, ev_out=True)
+    assert "ev_out" not in routed and torch.equal(routed["rgb"], raw["rgb"].clamp_min(1e-5))
+    loss = m.get_loss_dict({"col_out": routed, "prev_out": None, "next_out": None},
+                           {"col_batch": {"image": torch.rand(6, 3)}, "evs_batch": None})
+    assert set(loss) == {"rgb_loss"}
+    with pytest.raises(KeyError, match="ev_out"):
+        m.get_loss_dict({"col_out": None, "prev_out": routed, "next_out": routed},
+                        {"col_batch": None, "evs_batch": {"image": torch.rand(6, 1)}})
+    # a route that exists is unaffected
+    m2 = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="evs_rgb", num_levels=4, hidden_dim=32,
+                                               hidden_dim_color=32, grid_levels=1, grid_resolution=8), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4)
+    assert m2._plan()["mode"] == "evs_rgb" and not m2._plan()["unrouted"]
+
+
+def test_counter_summary_is_reported_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json carries per-group digests of the kernel sources (lsenerf_amd/provenance.py); bench.py nulls the
+    counter fields and says `traffic_stale` when the tree has moved on."""
+    from lsenerf_amd import provenance as pv
+    d = pv.source_digests()
+    assert set(d) == {"hash", "mlp"} and all(len(v) == 16 for v in d.values())
+    assert pv.counters_current({"source_digests": dict(d)}, "hash") and pv.counters_current({"source_digests": dict(d)}, "mlp")
+    assert not pv.counters_current({}, "hash") and not pv.counters_current({"source_digests": {"hash": "0" * 16}}, "hash")
+    # a one-byte change of a kernel source changes its group's digest and only that one
+    src = tmp_path / "csrc"
+    inc = tmp_path / "include"
+    src.mkdir(); inc.mkdir()
+    for name in {n for g in pv.GROUPS.values() for n in g}:
+        with open(pv._path(name), "rb") as f:
+            (inc if name == "lse_hip.h" else src).joinpath(name).write_bytes(f.read())
+    monkeypatch.setattr(pv, "_CSRC", str(src)); monkeypatch.setattr(pv, "_INCLUDE", str(inc))
+    assert pv.source_digests() == d
+    with open(src / "mlp_x6.h", "ab") as f:
+        f.write(b"\n")
+    d2 = pv.source_digests()
+    assert d2["hash"] == d["hash"] and d2["mlp"] != d["mlp"]
+    assert pv.counters_current({"source_digests": dict(d)}, "hash") and not pv.counters_current({"source_digests": dict(d)}, "mlp")
+
+
+def test_loading_a_grid_state_invalidates_what_was_derived_from_the_old_grid():
+    from lsenerf_amd.grid_estimator import LSEOccGridEstimator
+    a, b = LSEOccGridEstimator([-1.0, -1, -1, 1, 1, 1], 8, 2), LSEOccGridEstimator([-1.0, -1, -1, 1, 1, 1], 8, 2)
+    a.occs.fill_(0.25); a.binaries.fill_(True)
+    b._occ_mean_host = 0.0
+    v = b.grid_version
+    b.load_state_dict(a.state_dict())
+    assert b.grid_version == v + 1 and b._occ_mean_host is None and float(b.occs.mean()) == 0.25
+    v = b.grid_version
+    b._occ_mean_host = 0.25
+    b.mark_all_occupied(0.5)
+    assert b.grid_version == v + 1 and b._occ_mean_host is None
+    b.check_deferred_overflow()        # no count-free call was made: nothing to read, no device needed

@@ -39,4 +39,10 @@ try:      # keys other tools maintain in the same file (matrix_core_busy: tools/
             j[k] = v
 except OSError:
     pass
+# stamp: the hash kernels' sources these traffic numbers were measured on (bench.py nulls them when the tree has moved on);
+# the "mlp" stamp belongs to matrix_core_busy and is set by tools/collect_busy.py from the SQ-counter pass of the same tree
+sys.path.insert(0, '.')
+import importlib.util
+spec = importlib.util.spec_from_file_location('prov', 'lsenerf_amd/provenance.py'); prov = importlib.util.module_from_spec(spec); spec.loader.exec_module(prov)
+j.setdefault("source_digests", {})["hash"] = prov.source_digest("hash")
 json.dump(j, open('profiles/pmc_traffic.json', 'w'), indent=1)
