@@ -351,18 +351,25 @@ def context_composition(device, kind, steps=16, warmup=6):
       kind "cfg2": colour + previous-event + next-event bundle, 2316 / 597 / 597 rays (R:lse_nerf/lse_datamanager.py:135-144),
                    co_map routing, identity rgb mapper, powpow event mapper, learned ThreeToOne, rgb MSE + log-intensity event loss
                    (R:exp_configs/lsenerf_config.sh);
+      kind "cfg3": cfg 2 + the per-frame appearance embedding of the EVIMOv2 preset (evs_emb: 512 x 32 table, one id per ray;
+                   R:exp_configs/lsenerf_emb_config.sh:19, R:lse_nerf/lse_embeddings.py:19-44);
       kind "cfg4": BAD-NeRF: rgb only, 878 pixels x 4 virtual cameras = 3512 rays averaged per pixel (deblur), gradients w.r.t.
                    every ray's origin and direction for the pose optimiser (R:exp_configs/BADNERF_config.sh)."""
-    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
+    from lsenerf_amd import LSEEmbeddingConfig, LSENeRFModel, LSENeRFModelConfig, RayBundle
     from lsenerf_amd.optim import FlatAdam, FlatParams
     torch.manual_seed(96)
+    n_emb = 64
     if kind == "cfg2":
         cfg = LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow")
         sizes = (2316, 597, 597)
+    elif kind == "cfg3":     # R:exp_configs/lsenerf_emb_config.sh: cfg 2's routing + one learned 32-d embedding per training frame
+        cfg = LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow",
+                                 embed_config=LSEEmbeddingConfig(embedding_type="evs_emb"))
+        sizes, n_emb = (2316, 597, 597), 512
     else:
         cfg = LSENeRFModelConfig(use_mapping=False, map_mode="None", evs_mapping_method="None", rgb_loss_type="deblur")
         sizes = (878 * 4, 0, 0)
-    model = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(device).train()
+    model = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=n_emb).to(device).train()
     with torch.no_grad():
         model.field.mlp_base_grid.params.mul_(3000.0)
         model.field.mlp_base_mlp.params[-16 * 64:-15 * 64].mul_(6.0)
@@ -374,8 +381,8 @@ def context_composition(device, kind, steps=16, warmup=6):
         n = o.shape[0]
         return RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
                          camera_indices=torch.zeros(n, 1, dtype=torch.long, device=device),
-                         metadata={"appearance_id": torch.randint(0, 64, (n,), generator=g).to(device)})
-    if kind == "cfg2":
+                         metadata={"appearance_id": torch.randint(0, n_emb, (n,), generator=g).to(device)})
+    if kind in ("cfg2", "cfg3"):
         o, d = sphere_rays(sizes[0], g)
         col = bundle(o, d)
         o, d = sphere_rays(sizes[1], g)
@@ -430,12 +437,14 @@ def context_composition(device, kind, steps=16, warmup=6):
     snap = _snapshot(model, opt)
     graphed = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=320)
     graphed["rays_per_s"] = rays / (graphed["ms_per_step"] * 1e-3)
-    if kind == "cfg2":      # (cfg 4's rays come from poses the step itself updates: nothing to march ahead)
+    if kind in ("cfg2", "cfg3"):      # (cfg 4's rays come from poses the step itself updates: nothing to march ahead)
         _restore(model, opt, snap)
         graphed["marcher_prefetched"] = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=320,
                                                         prefetch=True)
         graphed["marcher_prefetched"]["rays_per_s"] = rays / (graphed["marcher_prefetched"]["ms_per_step"] * 1e-3)
     return {"workload": {"cfg2": "colour + prev + next event bundle (2316 / 597 / 597 rays), co_map routing, rgb + event loss",
+                         "cfg3": "cfg 2 with a per-frame appearance embedding (evs_emb, 512 embeddings x 32, R:exp_configs/lsenerf_emb_config.sh): "
+                                 "colour + prev + next event bundle (2316 / 597 / 597 rays), co_map routing, rgb + event loss",
                          "cfg4": "BAD-NeRF deblur: 878 pixels x 4 virtual cameras = 3512 rays, rgb loss on the 4-ray mean, pose gradients"}[kind]
                         + "; ONE packed pass per step (train_step_bundles), reference default sampler configuration, carved grid, "
                           "refresh every 16 steps inside the timing",
@@ -722,6 +731,8 @@ def main():
             line["m_packed"] = context_m_packed(device)
             torch.cuda.empty_cache()
             line["cfg2_composition"] = context_composition(device, "cfg2")
+            torch.cuda.empty_cache()
+            line["cfg3_composition"] = context_composition(device, "cfg3")
             torch.cuda.empty_cache()
             line["cfg4_composition"] = context_composition(device, "cfg4")
         if world == 1 and not args.no_cpu_baseline:

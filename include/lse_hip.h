@@ -104,9 +104,14 @@ int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, 
 int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_rays, int64_t *packed_info, int64_t *total,
                               lse_stream_t stream);
 /* nerfstudio VolumetricSampler.forward: "if num_samples == 0: create a single fake sample" (ray 0, starts = ends = 1,
- * packed_info[0] = (0, 1)) -- applied on the device to a device-side count (*n_dev == 0 -> 1).  Arrays need room for 1 sample. */
+ * packed_info[0] = (0, 1)) -- applied on the device to a device-side count (*n_dev == 0 -> 1).  Arrays need room for 1 sample.
+ * feat_x01 [C,3] / feat_sel [C] / feat_y [n_levels][y_level_stride floats] (each nullable; ABI 4): the visibility pre-pass's
+ * compacted survivor features that the main pass re-uses (lse_compact_features).  With no survivor they hold nothing for slot 0,
+ * where the fake sample lands: the slot is zeroed (the sample has zero extent -- weight and gradients exactly 0 -- so any FINITE
+ * features give the reference's outputs; uninitialised ones may hold NaN). */
 int lse_fake_sample_if_empty(int64_t *packed_info, int32_t n_rays, int64_t *n_dev, int32_t *ray_indices, float *t_starts,
-                             float *t_ends, lse_stream_t stream);
+                             float *t_ends, float *feat_x01, uint8_t *feat_sel, float *feat_y, int64_t y_level_stride,
+                             int32_t n_levels, int32_t n_features, lse_stream_t stream);
 
 /* Per-ray near / far planes of R:lse_nerf/lse_grid_estimator.py:83-92 in one launch (bit-identical to the torch ops):
  * near = max(near_plane, t_min[r]) (+ jitter[r] * step_size when jitter is given: stratified sampling),

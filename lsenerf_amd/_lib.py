@@ -54,7 +54,7 @@ SIGNATURES = {
     "lse_traverse_grids_slots": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I64, P, P, P, P, P],
     "lse_compact_ray_slots": [P, P, I64, P, I32, P, P, P, P],
     "lse_pack_info_from_counts": [P, I32, P, P, P],
-    "lse_fake_sample_if_empty": [P, I32, P, P, P, P, P],
+    "lse_fake_sample_if_empty": [P, I32, P, P, P, P, P, P, P, I64, I32, I32, P],
     "lse_ray_planes": [F32, F32, P, P, P, F32, I32, P, P, P],
     "lse_visibility_mask": [P, P, P, P, I32, F32, F32, P, P, P],
     "lse_visibility_mask_alpha": [P, P, I32, F32, F32, P, P, P],

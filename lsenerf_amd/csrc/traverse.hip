@@ -382,11 +382,23 @@ __global__ __launch_bounds__(64) void traverse_kernel(TraverseArgs a)
 }
 
 // nerfstudio's VolumetricSampler inserts ONE fake sample (ray 0, t_start = t_end = 1) when no ray produced any, so that nothing
-// downstream sees empty tensors; with the count on the device the same rule is applied there
+// downstream sees empty tensors; with the count on the device the same rule is applied there.
+// `feat_*`: the visibility pre-pass's compacted features of the survivors (positions, selector, level-major hash features), which
+// the main pass takes instead of encoding the survivors again.  With no survivor nothing was written there, and the fake sample
+// lands in slot 0: its slot is ZEROED -- finite whatever the allocator left behind.  The sample has zero extent (weight exactly 0,
+// every gradient through it exactly 0), so which finite features it carries cannot reach any output.
 __global__ void fake_sample_kernel(int64_t *__restrict__ packed, int64_t *__restrict__ n_dev, int32_t *__restrict__ ri,
-                                   float *__restrict__ ts, float *__restrict__ te)
+                                   float *__restrict__ ts, float *__restrict__ te, float *__restrict__ feat_x01,
+                                   uint8_t *__restrict__ feat_sel, float *__restrict__ feat_y, int64_t y_level_stride, int n_levels,
+                                   int n_feat)
 {
-    if (threadIdx.x == 0 && *n_dev == 0) {
+    if (*n_dev != 0) return;        // (read by every lane before lane 0 writes below: one wave, program order)
+    const int lane = threadIdx.x;
+    if (feat_x01 && lane < 3) feat_x01[lane] = 0.f;
+    if (feat_sel && lane == 0) feat_sel[0] = 0;
+    if (feat_y)
+        for (int i = lane; i < n_levels * n_feat; i += 64) feat_y[(int64_t)(i / n_feat) * y_level_stride + (i % n_feat)] = 0.f;
+    if (lane == 0) {
         packed[0] = 0;
         packed[1] = 1;
         ri[0] = 0;
@@ -560,13 +572,16 @@ extern "C" int lse_pack_info_from_counts(const int64_t *chunk_cnts, int32_t n_ra
 }
 
 extern "C" int lse_fake_sample_if_empty(int64_t *packed_info, int32_t n_rays, int64_t *n_dev, int32_t *ray_indices,
-                                        float *t_starts, float *t_ends, lse_stream_t stream)
+                                        float *t_starts, float *t_ends, float *feat_x01, uint8_t *feat_sel, float *feat_y,
+                                        int64_t y_level_stride, int32_t n_levels, int32_t n_features, lse_stream_t stream)
 {
     LSE_REQUIRE(n_rays >= 0, "lse_fake_sample_if_empty: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
     LSE_REQUIRE(packed_info && n_dev && ray_indices && t_starts && t_ends, "lse_fake_sample_if_empty: null pointer");
+    LSE_REQUIRE(!feat_y || (y_level_stride >= n_features && n_levels >= 1 && n_features >= 1),
+                "lse_fake_sample_if_empty: feat_y needs its level stride (floats) and shape");
     hipLaunchKernelGGL(fake_sample_kernel, dim3(1), dim3(64), 0, lse::as_stream(stream), packed_info, n_dev, ray_indices, t_starts,
-                       t_ends);
+                       t_ends, feat_x01, feat_sel, feat_y, y_level_stride, n_levels, n_features);
     return lse::check_launch("lse_fake_sample_if_empty");
 }
 

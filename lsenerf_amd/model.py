@@ -289,7 +289,13 @@ class VolumetricSampler(nn.Module):
             render_step_size=render_step_size, near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane,
             stratified=self.training, cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter, deferred=True,
             premarched=premarched)
-        ops.fake_sample_if_empty(packed, n_dev, ri, ts, te)     # "create a single fake sample" of forward(), on the device
+        # "create a single fake sample" of forward(), on the device.  The pre-pass features parked for exactly these buffers (the
+        # main pass takes them instead of encoding the survivors again) hold nothing for the slot the fake sample lands in
+        pp = getattr(self._packed_field, "_prepass", None) if self._packed_field is not None else None
+        feats = None
+        if pp is not None and pp["key"][:2] == (ts.data_ptr(), ri.data_ptr()) and pp["x01"].shape[0] > 0:
+            feats = (pp["x01"], pp["sel"], pp["y"])
+        ops.fake_sample_if_empty(packed, n_dev, ri, ts, te, features=feats)
         return ri, ts, te, packed, n_dev
 
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0, far_plane=None,

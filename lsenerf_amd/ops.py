@@ -252,11 +252,19 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
 
 
 @torch.no_grad()
-def fake_sample_if_empty(packed_info, n_dev, ray_indices, t_starts, t_ends):
-    """nerfstudio's single fake sample (ray 0, t = 1) when the device-side count is 0 (lse_fake_sample_if_empty); in place."""
+def fake_sample_if_empty(packed_info, n_dev, ray_indices, t_starts, t_ends, features=None):
+    """nerfstudio's single fake sample (ray 0, t = 1) when the device-side count is 0 (lse_fake_sample_if_empty); in place.
+    ``features = (x01 [C,3], selector [C], y [L,C,F])``: the parked pre-pass features of these very buffers -- slot 0 is zeroed
+    together with the insertion (no survivor means nothing was compacted into it)."""
+    fx = fs = fy = None
+    stride, L, F = 0, 0, 0
+    if features is not None:
+        x01, sel, y = features
+        fx, fs, fy = _f32(x01, "features.x01"), _chk(sel, torch.uint8, "features.selector"), _f32(y, "features.y")
+        L, stride, F = y.shape[0], y.shape[1] * y.shape[2], y.shape[2]
     _lib.call("lse_fake_sample_if_empty", _chk(packed_info, torch.int64, "packed_info"), packed_info.shape[0],
               _chk(n_dev, torch.int64, "n_dev"), _chk(ray_indices, torch.int32, "ray_indices"), _f32(t_starts, "t_starts"),
-              _f32(t_ends, "t_ends"), _stream())
+              _f32(t_ends, "t_ends"), fx, fs, fy, stride, L, F, _stream())
 
 
 @torch.no_grad()

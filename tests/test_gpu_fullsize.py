@@ -1,0 +1,158 @@
+"""The reference's three real step compositions at their REAL ray counts (R:lse_nerf/lse_datamanager.py:135-144 with
+R:lse_nerf/lse_config.py:24's 3512 rays per batch; R:lse_nerf/lse_pipeline.py:110-129 renders a colour, a previous-event and a
+next-event bundle per step), in the reference's default configuration of the path (L = 16 / T = 2^19 hash grid, 4-level 128^3
+occupancy grid carved by the reference's own update rule, cone 0.004, alpha_thre 0.01, visibility pre-pass on):
+
+  cfg 2  (R:exp_configs/lsenerf_config.sh)      2316 colour + 597 + 597 event rays, co_map routing, powpow event mapper
+  cfg 3  (R:exp_configs/lsenerf_emb_config.sh)  the same with a per-frame appearance embedding (evs_emb, 512 x 32)
+  cfg 4  (R:exp_configs/BADNERF_config.sh)      878 pixels x 4 virtual cameras = 3512 rays, deblur mean, pose gradients
+
+Three ways to run one step on the same parameters, rays, targets and stratified offsets must agree:
+  (i)   three separate model passes -- the reference's composition -- on the synchronising sampler,
+  (ii)  ONE packed pass (LSENeRFModel.train_step_bundles) with device-side sample counts, eager,
+  (iii) that pass replayed as a HIP graph (GraphedTrainStep, optimizer outside the graph so the parameters stay put).
+Size-independent properties checked: sample counts per ray equal bit for bit; losses within 2e-5; the FIRST-STEP flat gradient
+(before Adam turns summation noise into +-lr steps) within TOL_GRAD per parameter tensor and within TOL_GRAD_BLOCK hash level by
+hash level; ray gradients per ray."""
+import pytest
+import torch
+
+from tests.util import TOL_GRAD, TOL_GRAD_BLOCK, blockwise_nmax_err, hash_level_bounds, nmax_err, per_ray_grad_check, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(kind):
+    from lsenerf_amd import LSEEmbeddingConfig, LSENeRFModel, LSENeRFModelConfig, RayBundle
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    torch.manual_seed(96)
+    n_emb = 64
+    if kind == "cfg2":
+        cfg = LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow")
+        sizes = (2316, 597, 597)
+    elif kind == "cfg3":
+        cfg = LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow",
+                                 embed_config=LSEEmbeddingConfig(embedding_type="evs_emb"))
+        sizes, n_emb = (2316, 597, 597), 512
+    else:
+        cfg = LSENeRFModelConfig(use_mapping=False, map_mode="None", evs_mapping_method="None", rgb_loss_type="deblur")
+        sizes = (878 * 4, 0, 0)
+    m = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=n_emb).cuda().train()
+    with torch.no_grad():        # a trained-like field: an opaque band, so that the grid carves and the pre-pass culls
+        m.field.mlp_base_grid.params.mul_(3000.0)
+        m.field.mlp_base_mlp.params[-16 * 64:-15 * 64].mul_(6.0)
+        if getattr(m, "evs_mapper", None) is not None:
+            m.evs_mapper.pow_coeff.fill_(0.8)
+    opt = FlatAdam(FlatParams(m.get_param_groups()["fields"]), lr=1e-3, eps=1e-15)
+    for s in range(0, 64, 16):
+        m.update_occupancy_grid(s)
+    occ = float(m.occupancy_grid.binaries.float().mean())
+    assert 0.05 < occ < 0.95, occ
+    g = torch.Generator().manual_seed(7)
+
+    def bundle(n, seed, jitter_from=None):
+        o, d = random_rays(n, seed=seed)
+        if jitter_from is not None:          # the same pixels seen from the neighbouring event camera
+            o = jitter_from[0].cpu() + 0.01 * torch.randn(o.shape, generator=g)
+            d = jitter_from[1].cpu() + 0.01 * torch.randn(d.shape, generator=g)
+            d = d / d.norm(dim=-1, keepdim=True)
+        return RayBundle(origins=o.cuda().requires_grad_(True), directions=d.cuda().requires_grad_(True),
+                         camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"),
+                         metadata={"appearance_id": torch.randint(0, n_emb, (n,), generator=g).cuda()})
+    if kind == "cfg4":
+        o, d = random_rays(878, seed=3)
+        o4 = (o[:, None, :] + 0.005 * torch.randn(878, 4, 3, generator=g)).reshape(-1, 3)
+        d4 = d[:, None, :] + 0.005 * torch.randn(878, 4, 3, generator=g)
+        d4 = (d4 / d4.norm(dim=-1, keepdim=True)).reshape(-1, 3)
+        col = RayBundle(origins=o4.cuda().requires_grad_(True), directions=d4.cuda().requires_grad_(True),
+                        camera_indices=torch.zeros(3512, 1, dtype=torch.long, device="cuda"),
+                        metadata={"appearance_id": torch.zeros(3512, dtype=torch.long, device="cuda")})
+        bundles = [col, None, None]
+        batch = {"col_batch": {"image": torch.rand(878, 3, generator=g).cuda()}, "evs_batch": None}
+    else:
+        col, prev = bundle(sizes[0], 1), bundle(sizes[1], 2)
+        nxt = bundle(sizes[2], 0, jitter_from=(prev.origins.detach(), prev.directions.detach()))
+        bundles = [col, prev, nxt]
+        batch = {"col_batch": {"image": torch.rand(sizes[0], 3, generator=g).cuda()},
+                 "evs_batch": {"image": ((torch.rand(sizes[1], 1, generator=g) - 0.5) * 0.4).cuda()}}
+    jit = [torch.rand(len(b), generator=g).cuda() if b is not None else None for b in bundles]
+    return m, opt, bundles, batch, jit
+
+
+@pytest.mark.parametrize("kind", ["cfg2", "cfg3", "cfg4"])
+def test_real_step_compositions_at_full_size_three_passes_equal_packed_equal_graphed(kind):
+    from lsenerf_amd import ops
+    from lsenerf_amd.graph import GraphedTrainStep
+    m, opt, bundles, batch, jit = _build(kind)
+    live = [b for b in bundles if b is not None]
+    keys = [k for k, b in zip(("col_out", "prev_out", "next_out"), bundles) if b is not None]
+    names = {id(p): n for n, p in m.named_parameters()}
+    spans = {names[id(q)]: (off, off + q.numel()) for q, off in zip(opt.flat.params, opt.flat.offsets)}
+    assert "field.mlp_base_grid.params" in spans and len(spans) == len(opt.flat.params)
+
+    def collect(losses, outs):
+        res = {"loss": {k: float(v) for k, v in losses.items()}, "grad": opt.flat.grad.clone(),
+               "ray": [(b.origins.grad.clone(), b.directions.grad.clone()) for b in live],
+               "counts": [o["num_samples_per_ray"].clone() for o in outs]}
+        for b in live:
+            b.origins.grad = b.directions.grad = None
+        return res
+
+    # (i) the reference's composition: one model pass per bundle, synchronising sampler
+    m.deferred_counts = False
+    opt.zero_grad()
+    raws = [m.exec_get_outputs(b, jitter=j) for b, j in zip(live, jit)]
+    l3 = m.fused_loss_dict({k: r for k, r in zip(keys, raws)} | {k: None for k in ("col_out", "prev_out", "next_out") if k not in keys}, batch)
+    sum(l3.values()).backward()
+    r3 = collect(l3, raws)
+    kept = sum(int(c.sum()) for c in r3["counts"])
+    assert kept > 100 * 3510, kept                      # the real regime: a few hundred surviving samples per ray
+    # (ii) ONE packed pass, device-side counts, eager
+    m.deferred_counts = True
+    ops.SYNC_STATS.update(seconds=0.0, count=0)
+    opt.zero_grad()
+    out1, l1, _ = m.train_step_bundles(*bundles, batch, jitter=torch.cat([j for j in jit if j is not None]))
+    sum(l1.values()).backward()
+    assert ops.SYNC_STATS["count"] == 0
+    r1 = collect(l1, [out1[k] for k in keys])
+    # (iii) the same pass replayed as a HIP graph (optimizer outside: the parameters stay those of (i) and (ii)).
+    # The eager losses above still own their autograd graphs, and with them the AccumulateGrad nodes of the mapper scalars
+    # (pow_coeff, ThreeToOne weights), which are bound to the stream they were created on: a capture that runs backward through
+    # such a stale node touches the default stream (torch warns "AccumulateGrad node's stream does not match"; the HIP runtime
+    # segfaults in hipStreamEndCapture).  Drop them first -- GraphedTrainStep's docstring says so.
+    import gc
+    del raws, l3, out1, l1
+    gc.collect()
+    step = GraphedTrainStep(m, opt, *bundles, batch, ray_grads=True, jitter="input", optimizer_in_graph=False)
+    lg = step(*bundles, batch, jitter=torch.cat([j for j in jit if j is not None]))
+    rg = {"loss": {k: float(v) for k, v in lg.items()}, "grad": opt.flat.grad.clone(),
+          "ray": [step.ray_grads[k] for k, b in zip(("col", "prev", "next"), bundles) if b is not None],
+          "counts": [step.outputs[k]["num_samples_per_ray"].clone() for k in keys]}
+    step.check_overflow()
+    step.close()
+
+    levels = hash_level_bounds(m.field.mlp_base_grid.meta)
+    for name, other in (("packed", r1), ("graphed", rg)):
+        assert set(other["loss"]) == set(r3["loss"]) == ({"rgb_loss", "event_loss"} if kind != "cfg4" else {"rgb_loss"})
+        for a, b in zip(other["counts"], r3["counts"]):
+            assert torch.equal(a, b), name                                   # same samples, ray by ray
+        for k, v in r3["loss"].items():
+            assert abs(other["loss"][k] - v) <= 2e-5 * max(1.0, abs(v)), (name, k, other["loss"][k], v)
+        for pname, (lo, hi) in spans.items():
+            ref, got = r3["grad"][lo:hi], other["grad"][lo:hi]
+            if float(ref.abs().max()) == 0.0:
+                assert float(got.abs().max()) == 0.0, (name, pname)
+                continue
+            assert nmax_err(got, ref, 1e-30) < TOL_GRAD, (name, pname, nmax_err(got, ref, 1e-30))
+            if pname == "field.mlp_base_grid.params":
+                assert blockwise_nmax_err(got, ref, levels) < TOL_GRAD_BLOCK, (name, blockwise_nmax_err(got, ref, levels))
+        for (go, gd), (ro, rd) in zip(other["ray"], r3["ray"]):
+            per_ray_grad_check(go, ro, max_outliers=2)
+            per_ray_grad_check(gd, rd, max_outliers=2)
+    if kind == "cfg3":      # the embedding rows that no ray of the batch selected stay exactly zero, the others do not
+        lo, hi = spans["field.embedding_appearance.embedding.weight"]
+        rows = r1["grad"][lo:hi].view(512, 32)
+        used = torch.zeros(512, dtype=torch.bool, device="cuda")
+        for b in live:
+            used[b.metadata["appearance_id"]] = True
+        assert bool((rows[~used] == 0).all()) and float(rows[used].abs().amax(1).min()) > 0.0
