@@ -108,8 +108,25 @@ def build_workload(device, seed, kind="sphere"):
     return model, rb, target.to(device), jitter.to(device)
 
 
-def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None, sharded=None):
+def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None, sharded=None, graphed=None, exposed=None):
+    """One step of the headline workload.  ``exposed``: a list that collects (event, event) pairs around the blocking part of the
+    gradient exchange (the exchange modes that overlap collect theirs inside lsenerf_amd.dist)."""
     from lsenerf_amd import dist as ldist
+    if graphed is not None:
+        # N > 1, exchange mode "graphed": everything up to the backward pass is ONE replayed HIP graph (optimizer_in_graph=False),
+        # then the all-reduce of the flat gradient, then Adam -- three host calls per step (R:lse_nerf/lse_pipeline.py:95-98's DDP
+        # all-reduce sits at the same place: between backward and the optimizer)
+        loss = graphed(rb, None, None, {"col_batch": {"image": target}, "evs_batch": None}, jitter=jitter)["rgb_loss"]
+        ev = None
+        if exposed is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        ldist.allreduce_grads(opt.flat.grad)
+        if ev is not None:
+            ev[1].record()
+            exposed.append(ev)
+        opt.step(grad_scale=1.0 / world)
+        return graphed.outputs["col_out"]["num_samples_per_ray"].sum(), loss
     rb.origins.grad = None
     rb.directions.grad = None
     cfg = model.config
@@ -140,7 +157,14 @@ def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=No
     if exchange is not None:
         exchange.finish()          # the fine levels' table gradients have been in flight since the middle of the hash backward
     elif world > 1:
+        ev = None
+        if exposed is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         ldist.allreduce_grads(opt.flat.grad)
+        if ev is not None:
+            ev[1].record()
+            exposed.append(ev)
     opt.step(grad_scale=1.0 / world)
     return (n_dev if n_dev is not None else ri.shape[0]), loss
 
@@ -508,11 +532,15 @@ def cpu_baseline(seconds_budget=25.0):
     torch.set_num_threads(cores)
     f = FieldOracle("torch", num_embeddings=64, seed=96)
     m = ModelOracle(f, cone_angle=0.0, alpha_thre=0.0)
-    R = 16
+    # a bounded sample of the M workload itself ("the CPU run processes M in ray chunks with gradient accumulation"):
+    # 1024 of the 4096 radius-1.5-sphere rays x 1024 samples, processed in chunks of 128 rays (pytorch_fwd materialises 8 x [N,16,2]
+    # f32 per chunk = 134 MB; larger chunks are faster on the CPU: 84 / 155 / 178 rays/s for chunks of 8 / 32 / 64 rays on 8 cores),
+    # gradients accumulated over the chunks, one Adam step per pass; rays/s = 1024 / pass time, i.e. the rate is extrapolated linearly
+    # to the full batch (per-ray work is independent; the per-step constant -- Adam over the 67 MB torch-layout table -- is paid once
+    # per 1024 rays instead of once per 4096)
+    R, CHUNK = 1024, 128
     g = torch.Generator().manual_seed(0)
-    o = torch.rand(R, 3, generator=g) - 0.5
-    d = torch.randn(R, 3, generator=g)
-    d = d / d.norm(dim=-1, keepdim=True)
+    o, d = sphere_rays(R, g)
     step = m.render_step_size
     ri = torch.repeat_interleave(torch.arange(R), SAMPLES_PER_RAY)
     ts = (0.05 + step * torch.arange(SAMPLES_PER_RAY, dtype=torch.float32)).repeat(R)
@@ -520,17 +548,18 @@ def cpu_baseline(seconds_budget=25.0):
     target = torch.rand(R, 3, generator=g)
     aid = torch.randint(0, 64, (R,), generator=g)
     state = {}
-    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=8)      # warm-up
+    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=CHUNK)      # warm-up
     times = []
     t_all = time.time()
-    while len(times) < 5 and (time.time() - t_all) < seconds_budget:
+    while len(times) < 3 and (time.time() - t_all) < seconds_budget:
         t0 = time.time()
-        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=8)
+        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=CHUNK)
         times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": R / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{R} rays x {SAMPLES_PER_RAY} samples, {len(times)} timed train steps (median), torch-native field "
-                      f"(hash pytorch_fwd + nn.Linear MLPs + torch volrend + Adam), fp32, {cores} threads"}
+            "sample": f"{R} of the {RAYS_PER_GPU} SURVEY-8d sphere rays x {SAMPLES_PER_RAY} samples in chunks of {CHUNK} rays with gradient "
+                      f"accumulation, {len(times)} timed train steps (median; {med:.1f} s each), rate extrapolated linearly to the full "
+                      f"batch; torch-native field (hash pytorch_fwd + nn.Linear MLPs + torch volrend + Adam), fp32, {cores} threads"}
 
 
 def main():
@@ -578,6 +607,7 @@ def main():
     # LSE_BENCH_EXCHANGE=plain selects the single blocking all-reduce; =overlap / =split the two-launch hash backward of
     # dist.OverlappedGradExchange (measured at N = 1: the second launch costs 0.28 ms, more than the exchange it hides).
     # =sharded: dist.ShardedAdamExchange (reduce-scatter, Adam on 1/W of the buffer, all-gather).
+    # =graphed: the step up to the backward pass replayed as ONE HIP graph, then a blocking all-reduce, then Adam.
     exchange, pipeline, sharded = None, None, None
     mode = os.environ.get("LSE_BENCH_EXCHANGE", "pipelined" if world > 1 else "plain")
     if mode == "sharded":
@@ -593,11 +623,26 @@ def main():
         exchange = ldist.OverlappedGradExchange(flat, grid.params, grid.meta.offsets, split_level=min(6, grid.meta.n_levels - 1))
         exchange.install()
 
+    graphed = None
+    if mode == "graphed":       # replay (sampler .. backward) -> all-reduce -> Adam; the pre-pass is off as SURVEY 8d prescribes
+        from lsenerf_amd.graph import GraphedTrainStep
+        model.sampler.density_fn = None
+        graphed = GraphedTrainStep(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None}, ray_grads=True,
+                                   jitter="input", optimizer_in_graph=False)
+    exposed = [] if world > 1 else None
+    if pipeline is not None:
+        pipeline.exposed_events = exposed
+
+    def one_step():
+        return train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded, graphed, exposed)
+
     n_samples = 0
     for _ in range(args.warmup):
-        n_samples, _ = train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded)
+        n_samples, _ = one_step()
     if pipeline is not None:
         pipeline.flush()
+    if exposed is not None:
+        del exposed[:]
 
     # timed region: barrier + synchronize on both sides.  Only the two candidates for the dominant kernel (the hash
     # gather / scatter) carry HIP events here -- on the stream they are launched on -- because instrumenting every entry
@@ -608,7 +653,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_samples, loss = train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded)
+        n_samples, loss = one_step()
     if pipeline is not None:
         pipeline.flush()           # the K-th all-reduce + Adam belong to the timed K steps
     host_issue = time.perf_counter() - t0      # host time to ISSUE the K steps (the sampler's one sync per step included)
@@ -621,6 +666,15 @@ def main():
     elapsed = ldist.max_over_ranks(elapsed, device)
     n_samples = int(n_samples)                 # the device-side count of the last step, read once, after the timed region
     model.occupancy_grid.check_deferred_overflow()
+    # what the gradient exchange still costs per step after whatever overlap the mode has: stream time between the two events that
+    # bracket the wait for (or, in the blocking modes, the whole of) the collective; max over ranks like the step time
+    exchange_exposed_ms = None
+    if exposed is not None:
+        tot = sum(e0.elapsed_time(e1) for e0, e1 in exposed) / max(args.steps, 1)
+        exchange_exposed_ms = ldist.max_over_ranks(tot, device)
+        exposed = None
+        if pipeline is not None:
+            pipeline.exposed_events = None
 
     per_kernel = {}
     for name, e0, e1 in timing["events"]:
@@ -628,6 +682,10 @@ def main():
     dom_ms_all = {k: sum(v) / len(v) for k, v in per_kernel.items()}            # mean launch duration inside the timed region
     # per-entry-point breakdown: separate instrumented pass (same workload, not part of the timed K steps)
     bsteps = min(args.steps, 8)
+    if graphed is not None:     # (a replayed graph has no host hooks between its kernels: the breakdown pass runs the eager step)
+        graphed.close()
+        graphed = None
+        model.deferred_counts = True
     kern_ms, launches = _event_pass(lambda i: train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded),
                                     0, bsteps, None)
     if pipeline is not None:
@@ -684,7 +742,9 @@ def main():
                                    "chosen for 1024 samples per ray on average; sampler + fwd + bwd + Adam, grads w.r.t. rays included",
                        "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": n_samples / RAYS_PER_GPU, "samples_per_step": n_samples,
                        "render_step_size": model.config.render_step_size,
-                       "parallelism": f"dp{world}", "grad_exchange": mode},
+                       "parallelism": f"dp{world}", "grad_exchange": mode,
+                       "exchange_exposed_ms_per_step": exchange_exposed_ms,
+                       "exchange_bytes_per_step": 4 * flat.numel if world > 1 else 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "traffic_stale": None if stale is None else stale["hash"],

@@ -213,7 +213,9 @@ typedef struct lse_hash_bwd_opts {
     int32_t prefetch;           /* gran 6: fetch level l+1's dy / table operands before level l's cache pass (see hashgrid.hip) */
 } lse_hash_bwd_opts;
 void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
-/* bytes of `workspace` that lse_hash_bwd_ex needs for opts->replicas x the levels below opts->replica_levels (NULL = defaults) */
+/* bytes of `workspace` that lse_hash_bwd_ex needs for opts->replicas x the levels below opts->replica_levels (NULL = defaults).
+ * The replicated levels stop at the first level that would push ONE replica past 2 MB (grids whose coarse levels are already
+ * large gain nothing from replicas): 0 is a valid answer and means "no workspace, no replicas". */
 int64_t lse_hash_bwd_workspace_bytes(const lse_grid_desc *desc, const lse_hash_bwd_opts *opts);
 int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
                     float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end, int64_t n,

@@ -1417,9 +1417,16 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
     o->prefetch = 0;
 }
 
+// The replicas pay where a level is a few thousand lines that every wave of the launch adds to (16^3 .. 43^3: 1 MB per replica); for
+// a grid whose coarse levels are already big (base_res >= ~64 at T = 2^19: 4 hashed levels = 16 MB per replica, 268 MB for 16, all of
+// it swept by hash_bwd_reduce_replicas_kernel after every backward) they would cost memory and time for nothing: the replicated
+// levels stop at the first level that would push ONE replica past this budget.
+constexpr int64_t kReplicaBudgetFloats = (2 << 20) / (int64_t)sizeof(float);      // 2 MB per replica
+
 static int64_t replica_floats(const lse_grid_desc *desc, const lse_hash_bwd_opts &o, int *levels_out)
 {
     int lv = std::min<int>(o.replica_levels, desc->n_levels);
+    while (lv > 0 && (int64_t)2 * desc->offsets[lv] > kReplicaBudgetFloats) --lv;
     if (o.replicas < 2 || lv <= 0) { if (levels_out) *levels_out = 0; return 0; }
     if (levels_out) *levels_out = lv;
     return (int64_t)2 * desc->offsets[lv];        // floats per replica (level offsets are multiples of 8 entries)

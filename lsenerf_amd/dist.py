@@ -74,7 +74,7 @@ class OverlappedGradExchange:
 
     48.8 of the 48.9 MB of gradients belong to the hash table, and the hash backward is the LAST kernel of the backward
     pass, so a plain all-reduce has nothing to overlap with.  With this object installed the hash backward runs in two
-    launches (ops.HASH_BWD_SPLIT): levels >= ``split_level`` first -- at the default split 8 x 4 MB of the table -- whose
+    launches (ops.set_hash_bwd_hook(table, "split", ...)): levels >= ``split_level`` first -- at the default split 8 x 4 MB of the table -- whose
     slice of the flat gradient buffer is handed to an asynchronous all-reduce (RCCL runs it on its own stream) while the
     second launch computes the remaining levels; ``finish()`` then reduces the rest and waits.  Results are identical to
     ``allreduce_grads`` (same sum over ranks, element for element).  Requires optim.FlatParams (gradients accumulate in
@@ -90,7 +90,7 @@ class OverlappedGradExchange:
         idx = [i for i, p in enumerate(flat.params) if p is table_param]
         assert idx, "table parameter is not part of the FlatParams"
         base = flat.offsets[idx[0]]
-        self.flat = flat
+        self.flat, self.table_param = flat, table_param
         self.split_level = int(split_level)
         # table layout: level l occupies entries [offsets[l], offsets[l+1]) with 2 features each
         self.lo = base + 2 * int(level_offsets[split_level])
@@ -105,12 +105,14 @@ class OverlappedGradExchange:
         self._expected, self._seen = int(n_backwards), 0
 
     def install(self):
+        """Hook the hash backward of THIS table (ops.set_hash_bwd_hook: keyed by the table, so other models of the process --
+        an evaluation copy, a viewer thread -- keep their single-launch backward)."""
         from . import ops
-        ops.HASH_BWD_SPLIT = (self.split_level, self._first_part_ready)
+        ops.set_hash_bwd_hook(self.table_param, "split", (self.split_level, self._first_part_ready))
 
     def uninstall(self):
         from . import ops
-        ops.HASH_BWD_SPLIT = None
+        ops.set_hash_bwd_hook(self.table_param, "split", None)
 
     def _first_part_ready(self):
         if self._seen >= self._expected:
@@ -248,6 +250,9 @@ class GradPipeline:
         self.world = world if world is not None else world_size()
         self.sharded = sharded
         self.work, self.pending = None, False
+        # measurement hook: a list makes flush() bracket the wait for the collective with two events on the current stream; the time
+        # between them is what the exchange still costs the step AFTER the overlap (bench.py: exchange_exposed_ms_per_step)
+        self.exposed_events: Optional[list] = None
 
     def attach(self, estimator):
         estimator.after_march_hook = self.flush
@@ -266,12 +271,20 @@ class GradPipeline:
     def flush(self):
         """wait -> Adam (mean over ranks folded into grad_scale).  No-op when nothing is in flight."""
         if self.pending:
+            ev = None
+            if self.exposed_events is not None and torch.cuda.is_available():
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             if self.sharded is not None:
                 self.opt.step_count += 1
-                self.sharded.finish()
+                self.sharded.finish()      # (wait + Adam on 1/W + all-gather: the bracket then holds all three)
             else:
                 if self.work is not None:
                     self.work.wait()
+            if ev is not None:
+                ev[1].record()
+                self.exposed_events.append(ev)
+            if self.sharded is None:
                 self.opt.step(grad_scale=1.0 / self.world)
             self.work, self.pending = None, False
 

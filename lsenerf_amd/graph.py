@@ -120,7 +120,9 @@ class GraphedTrainStep:
     ``jitter``: "graph" draws the stratified offsets inside the graph; a tensor-valued call argument ``jitter=`` is copied
     into a static input instead when the object was built with ``jitter="input"``.
     ``prefetch_march=True`` (module docstring): announce the next step's rays with ``next_bundles=(col, prev, nxt)`` (and
-    ``next_jitter=`` for jitter="input") at every call; the next call must then be given exactly those rays."""
+    ``next_jitter=`` for jitter="input") at every call and hand the next call those very tensors, unmodified.  A call whose rays are
+    not the announced ones (other tensors, or the same ones written to in between) does not train on the wrong samples: the samples
+    marched ahead are dropped and the given rays marched before the replay (``remarched_unannounced`` counts these calls)."""
 
     def __init__(self, model, opt: FlatAdam, col: Optional[RayBundle], prev: Optional[RayBundle], nxt: Optional[RayBundle],
                  batch: Dict[str, object], ray_grads: bool = False, jitter: str = "graph", warmup: int = 3,
@@ -163,6 +165,8 @@ class GraphedTrainStep:
             self._losses_of.append(self.losses)
             self._outputs_of.append(self.outputs)
             self._ray_grads_of.append(self._collect_ray_grads())
+        self._announced = None       # identity of the rays the other buffer was marched for (see _signature)
+        self.remarched_unannounced = 0   # calls whose rays were not the announced ones (their samples were marched again)
         self._cur = 0                # the buffer that holds (or will be given) the samples of the rays in the static CURRENT bundles
         self._pm_version = None      # grid_version under which the other buffer was filled by the last replay; None: not filled
         self._last = 0
@@ -212,15 +216,16 @@ class GraphedTrainStep:
             with torch.cuda.stream(self._side), torch.no_grad():
                 self.model.premarch_bundles(self.next_col, self.next_prev, self.next_nxt, jitter=self.next_jitter, out=self._pm[1 - x])
 
-        saved = ops.BEFORE_HASH_BWD
+        table = self.model.field.mlp_base_grid.params
+        saved = ops.get_hash_bwd_hook(table, "before")
         try:
             if self.prefetch_fork == "start":
                 fork()
             else:
-                ops.BEFORE_HASH_BWD = fork
+                ops.set_hash_bwd_hook(table, "before", fork)       # (this model's table only)
             self._body(premarched=self._pm[x])
         finally:
-            ops.BEFORE_HASH_BWD = saved
+            ops.set_hash_bwd_hook(table, "before", saved)
         if not forked:          # (no hash backward ran: a frozen table)
             fork()
         main.wait_stream(self._side)
@@ -258,12 +263,28 @@ class GraphedTrainStep:
             elif jitter is not None:
                 raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
         if self.prefetch:
+            # the samples marched ahead belong to the rays that were ANNOUNCED: if the rays given now are not those very tensors,
+            # unmodified (same storage, same version counters; jitter likewise), the samples are dropped and these rays marched
+            if self._pm_version is not None and self._announced != self._signature((col, prev, nxt), jitter):
+                self._pm_version = None
+                self.remarched_unannounced += 1
             return self._replay_prefetch(next_bundles, next_jitter)
         if self.optimizer_in_graph:
             self.opt.prepare_step()
         self.graph.replay()
         self.replays += 1
         return self.losses
+
+    @staticmethod
+    def _signature(bundles, jitter):
+        """Identity of a set of rays as cheap as it gets: storage addresses, shapes and in-place version counters."""
+        sig = []
+        for b in bundles:
+            sig.append(None if b is None else tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (b.origins, b.directions)) +
+                       tuple((k, v.data_ptr(), v._version) for k, v in sorted(b.metadata.items()) if torch.is_tensor(v)) +
+                       tuple((n, getattr(b, n).data_ptr(), getattr(b, n)._version) for n in ("nears", "fars") if getattr(b, n) is not None))
+        sig.append(None if jitter is None else (jitter.data_ptr(), tuple(jitter.shape), jitter._version))
+        return sig
 
     def _replay_prefetch(self, next_bundles, next_jitter) -> Dict[str, Tensor]:
         est, x = self.model.occupancy_grid, self._cur
@@ -288,6 +309,7 @@ class GraphedTrainStep:
         self._graphs[x].replay()
         self.replays += 1
         self._pm_version = version if next_bundles is not None else None
+        self._announced = self._signature(next_bundles, next_jitter) if next_bundles is not None else None
         self._last, self._cur = x, 1 - x
         self.losses, self.outputs = self._losses_of[x], self._outputs_of[x]
         return self.losses

@@ -478,9 +478,10 @@ class _HashFn(torch.autograd.Function):
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
         opts = hash_bwd_opts_with_workspace(desc, x01.device)     # defaults + the coarse-level replica workspace
-        split = HASH_BWD_SPLIT
-        if BEFORE_HASH_BWD is not None:        # e.g. fork a side stream here: the scatter below is the last big kernel of the backward pass
-            BEFORE_HASH_BWD()
+        hooks = _HASH_BWD_HOOKS.get(table.data_ptr())      # per TABLE, not per process: other models in the process are untouched
+        split = hooks.get("split") if hooks else None
+        if hooks and hooks.get("before") is not None:     # e.g. fork a side stream here: the scatter below is the last big kernel of the backward pass
+            hooks["before"]()
         if split is not None and direct is not None and 0 < split[0] < meta.n_levels:
             # fine levels first (most of the table bytes); their gradients are final when the callback runs, so the caller
             # can start exchanging them while the coarse levels are still being computed (dist.OverlappedGradExchange)
@@ -613,8 +614,31 @@ class _MlpFn(torch.autograd.Function):
         return (None if direct is not None else d_params), d_in, d_bias, None, None, None, None, None, None, None, None
 
 
-BEFORE_HASH_BWD = None       # callable run (in the autograd thread, on the backward's stream) right before the hash backward is launched
-HASH_BWD_SPLIT = None        # (level, callback) installed by dist.OverlappedGradExchange: two launches, callback in between
+# Hooks into the hash backward, keyed by the TABLE they belong to (its storage address): a second model in the same process -- an
+# evaluation copy, the viewer thread nerfstudio runs beside training -- never sees the hooks of the model being trained.  (Until round
+# 3 these were two process-global variables.)
+#   "before": callable run (in the autograd thread, on the backward's stream) right before the hash backward is launched
+#   "split":  (level, callback) of dist.OverlappedGradExchange: two launches, callback in between
+_HASH_BWD_HOOKS: dict = {}
+
+
+def set_hash_bwd_hook(table: torch.Tensor, kind: str, value) -> None:
+    """Install (``value`` not None) or remove a hook of the hash backward of ``table`` (``kind``: "before" | "split")."""
+    assert kind in ("before", "split")
+    key = table.data_ptr()
+    h = _HASH_BWD_HOOKS.setdefault(key, {})
+    if value is None:
+        h.pop(kind, None)
+        if not h:
+            _HASH_BWD_HOOKS.pop(key, None)
+    else:
+        h[kind] = value
+
+
+def get_hash_bwd_hook(table: torch.Tensor, kind: str):
+    return _HASH_BWD_HOOKS.get(table.data_ptr(), {}).get(kind)
+
+
 DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated leaf .grad (see _direct_grad)
 SINGLE_PASS_MARCH = True   # False: always the published count pass + write pass
 FUSED_WGRAD = True    # False: materialised d_act + lse_mlp_wgrad (kept as an in-library cross-check)

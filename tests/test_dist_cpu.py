@@ -99,7 +99,8 @@ def _overlap_worker(rank, world, port, out):
     flat = FlatParams([other, table, tail])
     ex = ldist.OverlappedGradExchange(flat, table, level_offsets=(0, 32, 64, 96), split_level=1)
     ex.install()
-    assert ops.HASH_BWD_SPLIT[0] == 1
+    assert ops.get_hash_bwd_hook(table, "split")[0] == 1
+    assert ops.get_hash_bwd_hook(other, "split") is None          # keyed by the table: nothing else in the process is hooked
     res = []
     for use_split in (True, False):
         flat.zero_grad()
@@ -108,13 +109,13 @@ def _overlap_worker(rank, world, port, out):
         other.grad.add_(torch.randn(100, generator=g))
         table.grad[64:].add_(torch.randn(128, generator=g))
         if use_split:
-            ops.HASH_BWD_SPLIT[1]()
+            ops.get_hash_bwd_hook(table, "split")[1]()
         table.grad[:64].add_(torch.randn(64, generator=g))
         tail.grad.add_(torch.randn(7, generator=g))
         ex.finish()           # without the callback: falls back to one plain all-reduce
         res.append(flat.grad.clone())
     ex.uninstall()
-    assert ops.HASH_BWD_SPLIT is None
+    assert ops.get_hash_bwd_hook(table, "split") is None and not ops._HASH_BWD_HOOKS
     if rank == 0:
         torch.save(res, out)
     dist.barrier()
@@ -211,7 +212,7 @@ def _multi_backward_worker(rank, world, port, out):
         for _ in range(3):                          # three accumulating hash backwards: fine levels, callback, coarse levels
             table.grad[64:].add_(torch.randn(128, generator=g))
             if mode == "armed":
-                ops.HASH_BWD_SPLIT[1]()
+                ops.get_hash_bwd_hook(table, "split")[1]()
             table.grad[:64].add_(torch.randn(64, generator=g))
         other.grad.add_(torch.randn(100, generator=g))
         if mode == "armed":
@@ -221,9 +222,9 @@ def _multi_backward_worker(rank, world, port, out):
         res.append(flat.grad.clone())
     # an un-armed second callback in one step must raise instead of reducing the slice twice
     ex.begin_step(1)
-    ops.HASH_BWD_SPLIT[1]()
+    ops.get_hash_bwd_hook(table, "split")[1]()
     try:
-        ops.HASH_BWD_SPLIT[1]()
+        ops.get_hash_bwd_hook(table, "split")[1]()
         raised = False
     except RuntimeError:
         raised = True
@@ -294,6 +295,8 @@ def _pipeline_worker(rank, world, port, out):
         est = _ToyEstimator()
         sharded = ldist.ShardedAdamExchange(flat, lr=opt.lr, adam_fn=_adam_fn_cpu) if mode == "pipelined_sharded" else None
         pipe = ldist.GradPipeline(opt, world, sharded=sharded).attach(est) if mode != "plain" else None
+        if pipe is not None:
+            pipe.exposed_events = []      # the measurement hook of bench.py: no device here, so nothing is recorded and nothing breaks
         for step in range(4):
             # the visibility pre-pass reads the parameters: it must see the update of the previous step
             seen.append(est.sampling(lambda: float(flat.data.sum())))
@@ -307,7 +310,7 @@ def _pipeline_worker(rank, world, port, out):
         if pipe is not None:
             pipe.flush()
             pipe.flush()      # idempotent
-            assert opt.step_count == 4
+            assert opt.step_count == 4 and pipe.exposed_events == []
         finals.append(flat.data.clone())
     if rank == 0:
         torch.save({"finals": finals, "seen": seen}, out)

@@ -203,6 +203,18 @@ def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_ea
             d = (o_g.flat.data - o_e.flat.data).abs()
             assert float((d > 1e-5 * float(o_e.flat.data.abs().max())).float().mean()) < 0.02
     assert marched_again == [True, False, False, True, False, True]        # first call, refresh, nothing announced
+    assert step.remarched_unannounced == 0
+    # rays that were NOT the announced ones: announce steps[0], then call with steps[6] -- the samples marched ahead belong to other
+    # rays and must be dropped (the step must equal the eager step on steps[6], not train on steps[0]'s samples)
+    bundles, batch, jit = steps[5]
+    step(*bundles, batch, jitter=jit, next_bundles=steps[0][0], next_jitter=steps[0][2])
+    _eager_step(m_e, o_e, bundles, batch, jit, False)
+    bundles, batch, jit = steps[6]
+    l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit).items()}
+    l_e, _, _ = _eager_step(m_e, o_e, bundles, batch, jit, False)
+    assert step.remarched_unannounced == 1
+    for k in l_e:
+        assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (k, l_g[k], l_e[k])
     step.check_overflow()
     step.close()
 

@@ -341,3 +341,20 @@ def test_loading_a_grid_state_invalidates_what_was_derived_from_the_old_grid():
     b.mark_all_occupied(0.5)
     assert b.grid_version == v + 1 and b._occ_mean_host is None
     b.check_deferred_overflow()        # no count-free call was made: nothing to read, no device needed
+
+
+def test_hash_bwd_replica_workspace_is_bounded_by_a_byte_budget():
+    """16 replicas x the 4 coarsest levels is 16 MB for the default grid (levels of 16^3 .. 43^3 cells) -- and would be 268 MB for
+    a grid whose coarse levels are already hashed (base resolution 64 at T = 2^19), where replicas buy nothing: the replicated
+    levels stop at the first level that pushes one replica past 2 MB."""
+    import ctypes
+    from lsenerf_amd import _lib, ops
+    lib = _lib.load()
+    d = ops.make_grid_meta().desc()
+    assert lib.lse_hash_bwd_workspace_bytes(ctypes.byref(d), None) == 16 * 2 * 125568 * 4
+    big = ops.make_grid_meta(base_resolution=64, max_res=4096).desc()
+    per_replica = [2 * 4 * int(big.offsets[l]) for l in range(1, 5)]
+    assert per_replica[3] > (8 << 20)                                            # what the unbounded rule would replicate
+    got = lib.lse_hash_bwd_workspace_bytes(ctypes.byref(big), None)
+    keep = max([0] + [b for b in per_replica if b <= (2 << 20)])
+    assert got == 16 * keep and got <= 16 * (2 << 20)
