@@ -204,12 +204,14 @@ def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_ea
             assert float((d > 1e-5 * float(o_e.flat.data.abs().max())).float().mean()) < 0.02
     assert marched_again == [True, False, False, True, False, True]        # first call, refresh, nothing announced
     assert step.remarched_unannounced == 0
-    # rays that were NOT the announced ones: announce steps[0], then call with steps[6] -- the samples marched ahead belong to other
-    # rays and must be dropped (the step must equal the eager step on steps[6], not train on steps[0]'s samples)
-    bundles, batch, jit = steps[5]
+    # rays that were NOT the announced ones: the call for steps[6] (announced by the last loop iteration) announces steps[0], and the
+    # call after it brings steps[5] instead -- the samples marched ahead belong to other rays and must be dropped (the step must
+    # equal the eager step on steps[5], not train on steps[0]'s samples)
+    bundles, batch, jit = steps[6]
     step(*bundles, batch, jitter=jit, next_bundles=steps[0][0], next_jitter=steps[0][2])
     _eager_step(m_e, o_e, bundles, batch, jit, False)
-    bundles, batch, jit = steps[6]
+    assert step.remarched_unannounced == 0
+    bundles, batch, jit = steps[5]
     l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit).items()}
     l_e, _, _ = _eager_step(m_e, o_e, bundles, batch, jit, False)
     assert step.remarched_unannounced == 1
