@@ -20,6 +20,7 @@ namespace lse {
 struct Option { const char *name; std::atomic<int64_t> value; };
 static Option g_options[] = {
     {"hash_fwd_mapping", {4}},
+    {"hash_fwd_lds_levels", {0}},
     {"mlp_fwd_cfg", {28}},
     {"mlp_bwd_cfg", {28}},
     {"mlp_bwd_impl", {1}},

@@ -118,7 +118,7 @@ constexpr int kFwdItems = LSE_FWD_ITEMS;   // samples per lane -> 32 independent
 __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, const float *__restrict__ x,
                                                                const float2 *__restrict__ table,
                                                                float2 *__restrict__ y, int64_t n_cap, int64_t chunks,
-                                                               int mapping, const int64_t *__restrict__ n_dev)
+                                                               int mapping, const int64_t *__restrict__ n_dev, int l_first)
 {
     // n_cap: the level stride of y and the sample capacity the grid was sized for; n: the samples that exist (device-side
     // count when one is set: workgroups past it leave at once)
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
         // just that 4 MB table -- without binding whole levels to single XCDs, whose costs differ 3x between levels.
         level = (int)(bid / chunks);
         chunk = bid % chunks;
-    } else if (mapping == 4) {   // level-major, finest level first (short tail on a cheap level)
-        level = L - 1 - (int)(bid / chunks);
+    } else if (mapping == 4) {   // level-major, finest level first (short tail on a cheap level); levels < l_first are not part of
+        level = L - 1 - (int)(bid / chunks);       // this launch (grid sized for L - l_first levels: hash_fwd_lds_kernel serves them)
         chunk = bid % chunks;
     } else if ((L & 7) == 0 && mapping == 1) {   // XCD-affine, levels interleaved (A/B reference)
         const int per = L >> 3;
@@ -190,6 +190,61 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
         }
         const int64_t i = base + (int64_t)it * kFwdThreads;
         if (valid[it]) y[(int64_t)level * n_cap + i] = r;
+    }
+}
+
+// LDS-resident variant for the coarsest levels (BASELINE.json north_star: "coalesced HBM gathers with LDS-staged trilinear
+// interpolation"; option hash_fwd_lds_levels, A/B partner of the L2-resident schedule above).  A workgroup stages the WHOLE table of
+// one dense level in LDS with coalesced 8-byte loads (level 0: 16^3 = 32 KB, level 1: 23^3 = 95 KB; level 2 = 233 KB does not fit
+// the 160 KB of a CU), then walks a contiguous share of the samples: positions in, 8 ds_read_b64 gathers per sample, the same
+// multiply-adds in the same order as hash_fwd_kernel (bit-identical results), y out.  Consecutive samples of a ray fall into the same
+// coarse cell, so most gathers of a wave-instruction are LDS broadcasts.
+constexpr int kFwdLdsThreads = 1024;
+__global__ __launch_bounds__(kFwdLdsThreads) void hash_fwd_lds_kernel(GridParams g, int level, const float *__restrict__ x,
+                                                                      const float2 *__restrict__ table, float2 *__restrict__ y,
+                                                                      int64_t n_cap, const int64_t *__restrict__ n_dev)
+{
+    extern __shared__ float2 s_tab[];
+    const int64_t n = lse::clamp_count(n_cap, n_dev);
+    const LevelInfo li = level_info(g, level);
+    const float2 *__restrict__ tab = table + li.offset;
+    for (uint32_t e = threadIdx.x; e < li.size; e += kFwdLdsThreads) s_tab[e] = tab[e];
+    __syncthreads();
+    // contiguous share of this workgroup, in steps of one sample per thread (adjacent lanes = adjacent samples of a ray)
+    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + kFwdLdsThreads - 1) / kFwdLdsThreads * kFwdLdsThreads;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
+    float2 *__restrict__ yl = y + (int64_t)level * n_cap;
+    for (int64_t i0 = lo; i0 < hi; i0 += 2 * kFwdLdsThreads) {
+        float w[2][3];
+        uint32_t p[2][3];
+        bool valid[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int64_t i = i0 + it * kFwdLdsThreads + threadIdx.x;
+            valid[it] = i < hi;
+            const int64_t ii = valid[it] ? i : (hi - 1);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) pos_fract(x[ii * 3 + d], li.scale, w[it][d], p[it][d]);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            uint32_t idx[8];
+            corner_indices(li, p[it][0], p[it][1], p[it][2], idx);
+            float2 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = s_tab[idx[c]];
+            float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float wt = 1.f;
+                wt *= (c & 1) ? w[it][0] : 1.f - w[it][0];
+                wt *= (c & 2) ? w[it][1] : 1.f - w[it][1];
+                wt *= (c & 4) ? w[it][2] : 1.f - w[it][2];
+                r.x = fmaf(wt, v[c].x, r.x);
+                r.y = fmaf(wt, v[c].y, r.y);
+            }
+            if (valid[it]) yl[i0 + it * kFwdLdsThreads + threadIdx.x] = r;
+        }
     }
 }
 
@@ -1381,12 +1436,38 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(x01 && table && y, "lse_hash_fwd: null pointer");
     const int64_t chunks = (n + kFwdThreads * kFwdItems - 1) / (kFwdThreads * kFwdItems);
-    const int64_t blocks = chunks * g.n_levels;
-    LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
     const int mapping = (int)lse::option("hash_fwd_mapping");
-    hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, lse::as_stream(stream), g, x01,
+    // option hash_fwd_lds_levels = k: the k coarsest levels whose whole table fits one CU's LDS run in hash_fwd_lds_kernel (needs
+    // the default mapping 4, whose grid simply ends k levels earlier)
+    int lds_levels = 0;
+    if (mapping == 4) {
+        const int want = (int)std::min<int64_t>(lse::option("hash_fwd_lds_levels"), g.n_levels - 1);
+        while (lds_levels < want && (int64_t)(g.offsets[lds_levels + 1] - g.offsets[lds_levels]) * 8 <= 156 * 1024) ++lds_levels;
+    }
+    hipStream_t st = lse::as_stream(stream);
+    for (int l = 0; l < lds_levels; ++l) {
+        const int lds_bytes = (int)(g.offsets[l + 1] - g.offsets[l]) * 8;
+        static int attr_bytes = 0;
+        if (lds_bytes > attr_bytes) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_fwd_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) {
+                lse::set_error("lse_hash_fwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
+                return LSE_E_LAUNCH;
+            }
+            attr_bytes = lds_bytes;
+        }
+        // as many workgroups as fit the chip at once with this much LDS each (16 waves per workgroup: at most 2 per CU)
+        const int per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
+        const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(256 * per_cu, (n + 2 * kFwdLdsThreads - 1) / (2 * kFwdLdsThreads)));
+        hipLaunchKernelGGL(hash_fwd_lds_kernel, dim3((unsigned)wgs), dim3(kFwdLdsThreads), lds_bytes, st, g, l, x01,
+                           reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, lse::device_count());
+    }
+    const int64_t blocks = chunks * (g.n_levels - lds_levels);
+    LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
+    hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, st, g, x01,
                        reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping,
-                       lse::device_count());
+                       lse::device_count(), lds_levels);
     return lse::check_launch("lse_hash_fwd");
 }
 

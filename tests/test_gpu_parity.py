@@ -1035,3 +1035,30 @@ def test_mlp_fused_density_head_and_compact_output():
     assert nmax_err(phg.grad[:64 * 16 + 64 * 64], phc.grad[:64 * 16 + 64 * 64]) < TOL_GRAD
     assert nmax_err(phg.grad[64 * 16 + 64 * 64:][:3 * 64], phc.grad[64 * 16 + 64 * 64:][:3 * 64]) < TOL_GRAD
     assert nmax_err(xhg.grad, xhc.grad) < TOL_GRAD
+
+
+def test_hash_fwd_lds_resident_variant_is_bit_identical():
+    """Option hash_fwd_lds_levels (the "LDS-staged trilinear interpolation" BASELINE.json's north_star names, kept as the A/B partner
+    of the L2-resident level-major schedule, profiles/r04_hash_fwd_lds_ab.txt): the k coarsest levels are gathered from an LDS copy of
+    their table.  Same multiply-adds in the same order -> bit-identical features, for ragged counts, a device-side count below the
+    capacity, and a grid whose level 1 does not fit the LDS (the variant then stops at level 0)."""
+    from lsenerf_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    try:
+        for meta, n in ((ops.make_grid_meta(), 200003), (ops.make_grid_meta(n_levels=4, log2_hashmap_size=12), 777),
+                        (ops.make_grid_meta(base_resolution=24, max_res=1024), 65537)):
+            table = ((torch.rand(meta.n_params, generator=g) * 2 - 1) * 1e-2).cuda()
+            x = torch.rand(n, 3, generator=g).cuda()
+            x[: n // 2] = (x[:1] + 1e-3 * torch.arange(n // 2, device="cuda")[:, None]).clamp(0, 1)      # ray-like: neighbours share cells
+            _lib.set_option("hash_fwd_lds_levels", 0)
+            ref = ops.hash_encode(x, table, meta)
+            n_dev = torch.tensor([n - 1234 if n > 2000 else n - 7], dtype=torch.int64, device="cuda")
+            ref_dev = ops.hash_encode(x, table, meta, n_dev=n_dev)
+            for k in (1, 2, 5):
+                _lib.set_option("hash_fwd_lds_levels", k)
+                assert torch.equal(ops.hash_encode(x, table, meta), ref), (meta.n_levels, n, k)
+                got = ops.hash_encode(x, table, meta, n_dev=n_dev)
+                m = int(n_dev)
+                assert torch.equal(got[:, :m], ref_dev[:, :m]) and torch.equal(got[:, :m], ref[:, :m]), (meta.n_levels, n, k)
+    finally:
+        _lib.set_option("hash_fwd_lds_levels", 0)
