@@ -66,13 +66,15 @@ for mode in ("eager", "graphed", "graphed_prefetch"):
     curve = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    upcoming = batch_of(0)
     for it in range(STEPS):
         student.update_occupancy_grid(it)
-        col, prev, nxt, batch = batch_of(it)
+        col, prev, nxt, batch = upcoming          # the very tensors that were announced (the graph checks their identity)
+        upcoming = batch_of(it + 1)
         if mode == "graphed_prefetch":      # the next step's rays are announced one step early and marched on the side stream
             if step is None:
                 step = GraphedTrainStep(student, opt, col, prev, nxt, batch, prefetch_march=True)
-            losses = step(col, prev, nxt, batch, next_bundles=batch_of(it + 1)[:3])
+            losses = step(col, prev, nxt, batch, next_bundles=upcoming[:3])
         elif mode == "eager":
             opt.zero_grad()
             _, losses, _ = student.train_step_bundles(col, prev, nxt, batch)
@@ -88,6 +90,9 @@ for mode in ("eager", "graphed", "graphed_prefetch"):
     dt = time.perf_counter() - t0
     if step is not None:
         step.check_overflow()
+        if mode == "graphed_prefetch":
+            print("   calls whose rays were not the announced ones (re-marched):", step.remarched_unannounced)
+            assert step.remarched_unannounced == 0
     student.occupancy_grid.check_deferred_overflow()
     finite = bool(torch.isfinite(opt.flat.data).all())
     results[mode] = {"seconds": dt, "ms_per_step": dt / STEPS * 1e3, "finite_parameters": finite, "curve": curve,
