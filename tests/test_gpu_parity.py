@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import TOL_GRAD_BLOCK, blockwise_nmax_err, hash_level_bounds, rel_l2  # noqa: E402
+from tests.util import TOL_GRAD_BLOCK, blockwise_nmax_err, hash_level_bounds, mlp_row_bounds, rel_l2  # noqa: E402
 from tests.util import TOL_FWD, TOL_GRAD, nmax_err, random_binaries, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -1062,3 +1062,103 @@ def test_hash_fwd_lds_resident_variant_is_bit_identical():
                 assert torch.equal(got[:, :m], ref_dev[:, :m]) and torch.equal(got[:, :m], ref[:, :m]), (meta.n_levels, n, k)
     finally:
         _lib.set_option("hash_fwd_lds_levels", 0)
+
+
+@pytest.mark.parametrize("shape", ["head", "base"])
+def test_mlp_full_size_properties(shape):
+    """The fused MLPs at BASELINE.json's full size (N = 2^22 + 5 samples: a ragged last tile; the persistent grid then walks 131 073
+    32-sample tiles, 64 per wave), through properties that do not need an N-sized oracle:
+      * rows of the forward, and rows of the input gradient, on a random subset == a float64 torch evaluation of those rows alone
+        (a row depends on its own input row -- and its ray's bias row -- only);
+      * additivity over samples: the weight (and per-row bias) gradient of the whole batch == the sum of the gradients of 7 unequal
+        chunks launched separately (different tile -> wave assignments, different atomic orders);
+      * linearity in the upstream gradient: bwd(g1 - 2 g2) == bwd(g1) - 2 bwd(g2) for the parameter gradient."""
+    from lsenerf_amd import _lib
+    from oracle.field import TcnnMLP
+    ops = _ops()
+    N = (1 << 22) + 5
+    g = torch.Generator(device="cuda").manual_seed(11)
+    head = shape == "head"
+    in_dim, nl, act = (16, 3, "Sigmoid") if head else (32, 2, None)
+    om = TcnnMLP(in_dim, nl, 64, 16, act)
+    om.in_pad = in_dim
+    om.shapes[0] = (64, in_dim)
+    om.n_params = sum(a * b for a, b in om.shapes)
+    params = om.init_params(torch.Generator().manual_seed(3)).cuda()
+    meta = ops.MlpMeta(in_dim, 64, nl - 1, _lib.LSE_ACT_SIGMOID if head else _lib.LSE_ACT_NONE,
+                       _lib.LSE_IN_ROWMAJOR if head else _lib.LSE_IN_LEVELMAJOR)
+    if head:
+        x = torch.randn(N, in_dim, device="cuda", generator=g)
+        R = 4099                                                     # rays of very different lengths, ray-sorted samples
+        cuts = torch.sort(torch.randint(1, N, (R - 1,), device="cuda", generator=g)).values
+        bounds = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), cuts, torch.tensor([N], device="cuda")])
+        cnt = bounds[1:] - bounds[:-1]
+        packed = torch.stack([bounds[:-1], cnt], -1).contiguous()
+        ridx = torch.repeat_interleave(torch.arange(R, device="cuda", dtype=torch.int32), cnt)
+        bias = torch.randn(R, 64, device="cuda", generator=g) * 0.3
+    else:
+        x = torch.randn(in_dim // 2, N, 2, device="cuda", generator=g)          # level-major
+        bias = ridx = packed = None
+
+    def run(lo, hi, gout, want_in=False):
+        """forward + backward of samples [lo, hi) (chunk boundaries on ray boundaries for the head): (out, d_params, d_bias, d_in)"""
+        p = params.clone().requires_grad_(True)
+        if head:
+            r0, r1 = int(ridx[lo]), int(ridx[hi - 1]) + 1
+            xs = x[lo:hi].clone().requires_grad_(want_in)
+            b = bias[r0:r1].clone().requires_grad_(True)
+            pk = packed[r0:r1].clone()
+            pk[:, 0] -= lo
+            out = ops.fused_mlp(p, xs, meta, hi - lo, b, (ridx[lo:hi] - r0).contiguous(), pk)
+        else:
+            xs = x[:, lo:hi].contiguous().requires_grad_(want_in)
+            b = None
+            out = ops.fused_mlp(p, xs, meta, hi - lo)
+        out.backward(gout[lo:hi])
+        db = None
+        if head:
+            db = torch.zeros_like(bias)
+            db[r0:r1] = b.grad
+        return out.detach(), p.grad, db, (xs.grad if want_in else None)
+
+    g1 = torch.randn(N, 16, device="cuda", generator=g)
+    out, dp, db, din = run(0, N, g1, want_in=True)
+    # ---- rows against float64
+    sub = torch.randint(0, N, (4096,), device="cuda", generator=g)
+    sub[:3] = torch.tensor([0, N - 1, N - 5], device="cuda")                         # first row, last row, first row of the ragged tile
+    Ws = [W.double() for W in om.matrices(params.cpu())]
+    xr = (x[sub] if head else x[:, sub].permute(1, 0, 2).reshape(-1, in_dim)).double().cpu().requires_grad_(True)
+    h = xr @ Ws[0].t()
+    if head:
+        h = h + bias[ridx[sub].long()].double().cpu()
+    h = torch.relu(h)
+    for W in Ws[1:-1]:
+        h = torch.relu(h @ W.t())
+    ref = h @ Ws[-1].t()
+    if head:
+        ref = torch.sigmoid(ref)
+    assert nmax_err(out[sub], ref) < TOL_FWD
+    ref.backward(g1[sub].double().cpu())
+    din_rows = din[sub] if head else din[:, sub].permute(1, 0, 2).reshape(-1, in_dim)
+    assert nmax_err(din_rows, xr.grad) < TOL_GRAD
+    # ---- additivity over samples
+    if head:
+        ray_cuts = [0, 7, 500, 1203, 2048, 3000, 4000, R]
+        cuts_s = [int(bounds[r]) for r in ray_cuts]
+    else:
+        cuts_s = [0, 33, 100001, 1 << 20, (1 << 21) + 17, 3000000, 4000000, N]
+    dp_sum, db_sum = torch.zeros_like(dp), (torch.zeros_like(db) if head else None)
+    for lo, hi in zip(cuts_s[:-1], cuts_s[1:]):
+        if hi > lo:
+            _, dpc, dbc, _ = run(lo, hi, g1)
+            dp_sum += dpc
+            if head:
+                db_sum += dbc
+    assert nmax_err(dp_sum, dp, 1e-12) < TOL_GRAD and blockwise_nmax_err(dp_sum, dp, mlp_row_bounds(om)) < TOL_GRAD_BLOCK
+    if head:
+        assert nmax_err(db_sum, db, 1e-12) < TOL_GRAD
+    # ---- linearity in the upstream gradient
+    g2 = torch.randn(N, 16, device="cuda", generator=g)
+    _, dp2, _, _ = run(0, N, g2)
+    _, dp12, _, _ = run(0, N, g1 - 2.0 * g2)
+    assert nmax_err(dp12, dp - 2.0 * dp2, 1e-12) < TOL_GRAD
