@@ -533,33 +533,40 @@ def cpu_baseline(seconds_budget=25.0):
     f = FieldOracle("torch", num_embeddings=64, seed=96)
     m = ModelOracle(f, cone_angle=0.0, alpha_thre=0.0)
     # a bounded sample of the M workload itself ("the CPU run processes M in ray chunks with gradient accumulation"):
-    # 1024 of the 4096 radius-1.5-sphere rays x 1024 samples, processed in chunks of 128 rays (pytorch_fwd materialises 8 x [N,16,2]
-    # f32 per chunk = 134 MB; larger chunks are faster on the CPU: 84 / 155 / 178 rays/s for chunks of 8 / 32 / 64 rays on 8 cores),
-    # gradients accumulated over the chunks, one Adam step per pass; rays/s = 1024 / pass time, i.e. the rate is extrapolated linearly
-    # to the full batch (per-ray work is independent; the per-step constant -- Adam over the 67 MB torch-layout table -- is paid once
-    # per 1024 rays instead of once per 4096)
-    R, CHUNK = 1024, 128
+    # SURVEY-8d sphere rays x 1024 samples, processed in chunks of 128 rays (pytorch_fwd materialises 8 x [N,16,2] f32 per chunk =
+    # 134 MB; larger chunks are faster on the CPU: 84 / 155 / 178 rays/s for chunks of 8 / 32 / 64 rays on 8 cores), gradients
+    # accumulated over the chunks, one Adam step per pass.  How many of the 4096 rays a pass takes is set by a 256-ray probe pass so
+    # that one pass costs ~8 s on this box's cores -- the whole batch where the CPU is fast enough (the MI355X box's 16-core share:
+    # ~540 rays/s) -- and rays/s = rays / pass time (per-ray work is independent; the per-step constant, Adam over the 67 MB
+    # torch-layout table, is paid once per pass)
+    CHUNK = 128
     g = torch.Generator().manual_seed(0)
-    o, d = sphere_rays(R, g)
+    o_all, d_all = sphere_rays(RAYS_PER_GPU, g)
+    target_all = torch.rand(RAYS_PER_GPU, 3, generator=g)
+    aid_all = torch.randint(0, 64, (RAYS_PER_GPU,), generator=g)
     step = m.render_step_size
-    ri = torch.repeat_interleave(torch.arange(R), SAMPLES_PER_RAY)
-    ts = (0.05 + step * torch.arange(SAMPLES_PER_RAY, dtype=torch.float32)).repeat(R)
-    te = ts + step
-    target = torch.rand(R, 3, generator=g)
-    aid = torch.randint(0, 64, (R,), generator=g)
     state = {}
-    cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=CHUNK)      # warm-up
+
+    def one_pass(R):
+        ri = torch.repeat_interleave(torch.arange(R), SAMPLES_PER_RAY)
+        ts = (0.05 + step * torch.arange(SAMPLES_PER_RAY, dtype=torch.float32)).repeat(R)
+        t0 = time.time()
+        cpu_train_step_packed(m, o_all[:R], d_all[:R], ri, ts, ts + step, target_all[:R], aid_all[:R], state, ray_chunk=CHUNK)
+        return time.time() - t0
+
+    one_pass(CHUNK)                                           # warm-up (allocator, thread pool, optimizer state)
+    probe = one_pass(2 * CHUNK)
+    R = int(min(RAYS_PER_GPU, max(2 * CHUNK, (8.0 / probe) * 2 * CHUNK)) // CHUNK * CHUNK)
     times = []
     t_all = time.time()
-    while len(times) < 3 and (time.time() - t_all) < seconds_budget:
-        t0 = time.time()
-        cpu_train_step_packed(m, o, d, ri, ts, te, target, aid, state, ray_chunk=CHUNK)
-        times.append(time.time() - t0)
+    while len(times) < 3 and (not times or (time.time() - t_all) + times[-1] < seconds_budget):
+        times.append(one_pass(R))
     med = sorted(times)[len(times) // 2]
     return {"value": R / med, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{R} of the {RAYS_PER_GPU} SURVEY-8d sphere rays x {SAMPLES_PER_RAY} samples in chunks of {CHUNK} rays with gradient "
-                      f"accumulation, {len(times)} timed train steps (median; {med:.1f} s each), rate extrapolated linearly to the full "
-                      f"batch; torch-native field (hash pytorch_fwd + nn.Linear MLPs + torch volrend + Adam), fp32, {cores} threads"}
+                      f"accumulation, {len(times)} timed train steps (median; {med:.1f} s each)"
+                      + ("" if R == RAYS_PER_GPU else ", rate extrapolated linearly to the full batch")
+                      + f"; torch-native field (hash pytorch_fwd + nn.Linear MLPs + torch volrend + Adam), fp32, {cores} threads"}
 
 
 def main():
