@@ -218,6 +218,19 @@ def _restore(model, opt, snap):
     est._invalidate_occ_mean()
 
 
+def _drop_autograd_graphs(holder):
+    """Forget the outputs of the last EAGER step before a step of the same model is captured.  They own their autograd graph and with
+    it the AccumulateGrad nodes of the small torch-side parameters, which stay bound to the stream they were created on (the default
+    stream); a capture whose backward runs through such a stale node leaves the capturing stream -- torch warns, and the HIP runtime
+    can crash in hipStreamEndCapture (lsenerf_amd.graph.GraphedTrainStep's docstring; found with tests/test_gpu_fullsize.py)."""
+    import gc
+    if isinstance(holder, dict):
+        holder.clear()
+    elif hasattr(holder, "last"):
+        holder.last = None
+    gc.collect()
+
+
 def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None, prefetch=False):
     """The same step as ONE replayed HIP graph (lsenerf_amd.graph.GraphedTrainStep: device-side sample counts, staged Adam
     scalars, jitter drawn inside the graph; the occupancy refresh stays an eager in-place call between replays).
@@ -324,6 +337,7 @@ def context_default_config(device, steps=20, warmup=6):
 
     ms, kern, launches = _timed_steps(step, steps, warmup)
     kept = int(step.last["num_samples_per_ray"].sum())
+    _drop_autograd_graphs(step)      # (the eager outputs own their autograd graph: see _drop_autograd_graphs)
     snap = _snapshot(model, opt)
     graphed = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None}, steps, warmup,
                               refresh_from=320)
@@ -457,6 +471,7 @@ def context_composition(device, kind, steps=16, warmup=6):
     assert n_sync_deferred == 0
     kern, launches = _event_pass(step, warmup + steps, 8, None)
     kept = sum(int(v["num_samples_per_ray"].sum()) for v in last["out"].values() if v is not None)
+    _drop_autograd_graphs(last)
     rays = sum(sizes)
     snap = _snapshot(model, opt)
     graphed = _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=320)
@@ -784,6 +799,8 @@ def main():
                                "Python + launch time and the host runs ahead of the GPU",
             "loss": float(loss.detach()),
         }
+        del loss
+        _drop_autograd_graphs({})
         if world == 1 and not args.no_context:
             # the headline workload as one replayed graph (pre-pass off as SURVEY 8d prescribes: no density_fn on the sampler)
             model.sampler.density_fn = None

@@ -41,33 +41,85 @@ from .optim import FlatAdam
 from .rays import RayBundle
 
 
-def _static_like(b: Optional[RayBundle], requires_grad: bool) -> Optional[RayBundle]:
-    if b is None:
-        return None
-    c = lambda t: None if t is None else t.detach().clone()
-    return RayBundle(origins=c(b.origins).requires_grad_(requires_grad), directions=c(b.directions).requires_grad_(requires_grad),
-                     pixel_area=c(b.pixel_area), camera_indices=c(b.camera_indices), nears=c(b.nears), fars=c(b.fars),
-                     times=c(b.times), metadata={k: c(v) for k, v in b.metadata.items()})
+def _static_bundles(bundles: Sequence[Optional[RayBundle]], requires_grad: bool) -> Tuple[Optional[RayBundle], ...]:
+    """Static copies of the (up to three) bundles of a step whose fields are ROW BLOCKS OF ONE BUFFER PER FIELD: the step joins its
+    bundles into one (RayBundle.cat), and for such parts the join is the buffer itself -- no concatenation kernels inside the graph
+    (four forward, and the split of the ray gradients backward), and with ``requires_grad`` the one leaf per field is that buffer:
+    the ray gradients of all bundles arrive in ``buffer.grad`` (``GraphedTrainStep.ray_grads`` hands out its row blocks)."""
+    given = [b for b in bundles if b is not None]
+    if not given:
+        return tuple(None for _ in bundles)
+    joined = RayBundle.cat([RayBundle(origins=b.origins.detach(), directions=b.directions.detach(), pixel_area=b.pixel_area,
+                                      camera_indices=b.camera_indices, nears=b.nears, fars=b.fars, times=b.times,
+                                      metadata=dict(b.metadata)) for b in given]) if len(given) > 1 else given[0]
+    c = lambda t: None if t is None else t.detach().clone().contiguous()
+    base = RayBundle(origins=c(joined.origins).requires_grad_(requires_grad), directions=c(joined.directions).requires_grad_(requires_grad),
+                     pixel_area=c(joined.pixel_area), camera_indices=c(joined.camera_indices), nears=c(joined.nears), fars=c(joined.fars),
+                     times=c(joined.times), metadata={k: c(v) for k, v in joined.metadata.items()})
+    if len(given) == 1:
+        return tuple(base if b is not None else None for b in bundles)
+    out, lo = [], 0
+    for b in bundles:
+        if b is None:
+            out.append(None)
+            continue
+        hi = lo + len(b)
+        # the row blocks are plain windows for copying the inputs in: cut WITHOUT autograd -- a view made with grad mode on would own an
+        # edge to its buffer's AccumulateGrad node and keep that node alive from construction on, bound to the construction-time
+        # stream; a capture whose backward runs through it crashes the HIP runtime in hipStreamEndCapture (see the class docstring)
+        with torch.no_grad():
+            cut = lambda t: None if t is None else t[lo:hi]
+            blk = RayBundle(origins=cut(base.origins), directions=cut(base.directions), pixel_area=cut(base.pixel_area),
+                            camera_indices=cut(base.camera_indices), nears=cut(base.nears), fars=cut(base.fars), times=cut(base.times),
+                            metadata={k: cut(v) for k, v in base.metadata.items()})
+        out.append(blk)
+        lo = hi
+    return tuple(out)
 
 
-def _copy_bundle(dst: Optional[RayBundle], src: Optional[RayBundle]) -> None:
+def _leaf(t: Tensor) -> Tensor:
+    """The tensor that owns ``t``'s gradient: ``t`` itself, or the buffer it is a row block of."""
+    return t if t._base is None else t._base
+
+
+def _copy_pairs(dst: Optional[RayBundle], src: Optional[RayBundle], pairs: list) -> None:
+    """Append the (static tensor, given tensor) pairs of one bundle to ``pairs`` (checked: same composition as captured)."""
     if (dst is None) != (src is None):
         raise ValueError("the batch composition of a captured step is fixed: a bundle appeared or disappeared")
     if dst is None:
         return
     if len(dst) != len(src):
         raise ValueError(f"the batch composition of a captured step is fixed: {len(dst)} rays captured, {len(src)} given")
-    with torch.no_grad():
-        for name in ("origins", "directions", "pixel_area", "camera_indices", "nears", "fars", "times"):
-            d, s = getattr(dst, name), getattr(src, name)
-            if (d is None) != (s is None):
-                raise ValueError(f"RayBundle.{name} was {'set' if d is not None else 'absent'} at capture")
-            if d is not None:
+    for name in ("origins", "directions", "pixel_area", "camera_indices", "nears", "fars", "times"):
+        d, s = getattr(dst, name), getattr(src, name)
+        if (d is None) != (s is None):
+            raise ValueError(f"RayBundle.{name} was {'set' if d is not None else 'absent'} at capture")
+        if d is not None:
+            pairs.append((d, s))
+    if set(dst.metadata) != set(src.metadata):
+        raise ValueError("RayBundle.metadata keys differ from the captured step's")
+    for k, v in dst.metadata.items():
+        pairs.append((v, src.metadata[k]))
+
+
+@torch.no_grad()
+def _run_copies(pairs: list) -> None:
+    """All input copies of a step in as few launches as possible.  One ``copy_`` per tensor is a ~5 us kernel each, and a 3-bundle
+    step with prefetching has 26 of them queued in front of every replay: 0.125 ms of a 2.6 ms step (rocprofv3 timeline,
+    tools/graph_timeline.py).  ``torch._foreach_copy_`` moves each group of same-typed device tensors with one multi-tensor kernel."""
+    pairs = [(d, s) for d, s in pairs if d.data_ptr() != s.data_ptr() or d.shape != s.shape]      # already in place: nothing to do
+    groups: Dict[tuple, list] = {}
+    for d, s in pairs:
+        if d.shape != s.shape:
+            raise ValueError(f"a static input of shape {tuple(d.shape)} was given a tensor of shape {tuple(s.shape)}")
+        key = (d.dtype, s.dtype, s.device)
+        groups.setdefault(key, []).append((d, s))
+    for (dd, sd, sdev), items in groups.items():
+        if len(items) > 1 and dd == sd and sdev == items[0][0].device and hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_([d for d, _ in items], [s for _, s in items], non_blocking=True)
+        else:
+            for d, s in items:
                 d.copy_(s, non_blocking=True)
-        if set(dst.metadata) != set(src.metadata):
-            raise ValueError("RayBundle.metadata keys differ from the captured step's")
-        for k, v in dst.metadata.items():
-            v.copy_(src.metadata[k], non_blocking=True)
 
 
 def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool=None):
@@ -136,13 +188,14 @@ class GraphedTrainStep:
         self.optimizer_in_graph = bool(optimizer_in_graph)
         self._deferred_before = (model.deferred_counts, model.deferred_max_slots)
         model.deferred_counts, model.deferred_max_slots = True, 1 << 62     # nothing inside the graph may wait for the host
-        self.col, self.prev, self.nxt = (_static_like(b, ray_grads) for b in (col, prev, nxt))
+        self.col, self.prev, self.nxt = _static_bundles((col, prev, nxt), ray_grads)
         self.batch = self._static_batch(batch)
         n_total = sum(len(b) for b in (self.col, self.prev, self.nxt) if b is not None)
         dev = opt.flat.data.device
         self.jitter = torch.rand(n_total, device=dev) if jitter == "input" else None
         self.losses: Dict[str, Tensor] = {}
         self.outputs = None
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.prefetch = bool(prefetch_march)
         assert prefetch_fork in ("start", "hash_bwd")
         self.prefetch_fork = prefetch_fork
@@ -151,7 +204,7 @@ class GraphedTrainStep:
             self.graph = capture_body(self._body, opt, model.occupancy_grid, warmup)
             return
         # -- marcher of the next step on a side stream: two graphs alternate between two sample buffers
-        self.next_col, self.next_prev, self.next_nxt = (_static_like(b, False) for b in (col, prev, nxt))
+        self.next_col, self.next_prev, self.next_nxt = _static_bundles((col, prev, nxt), False)
         self.next_jitter = torch.rand(n_total, device=dev) if jitter == "input" else None
         with torch.no_grad():
             self._pm = [model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter) for _ in range(2)]
@@ -184,12 +237,15 @@ class GraphedTrainStep:
     def _body(self, premarched=None):
         self.opt.zero_grad()
         for b in (self.col, self.prev, self.nxt):
-            if b is not None and b.origins.requires_grad:
-                b.origins.grad = None
-                b.directions.grad = None
+            if b is not None and _leaf(b.origins).requires_grad:
+                _leaf(b.origins).grad = None
+                _leaf(b.directions).grad = None
         out, losses, _ = self.model.train_step_bundles(self.col, self.prev, self.nxt, self.batch, jitter=self.jitter,
                                                        premarched=premarched)
-        sum(losses.values()).backward()
+        # backward of rgb_loss + event_loss without forming the sum: every root gets the upstream gradient 1 from one static tensor
+        # (the sum, its backward and the two ones_like fills were five ~5 us launches of every replay)
+        vals = list(losses.values())
+        torch.autograd.backward(vals, [self._one] * len(vals))
         if self.optimizer_in_graph:
             self.opt.step_staged(self.grad_scale)
         self.losses, self.outputs = losses, out
@@ -231,8 +287,21 @@ class GraphedTrainStep:
         main.wait_stream(self._side)
 
     def _collect_ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
-        return {k: (None if b is None or not b.origins.requires_grad else (b.origins.grad, b.directions.grad))
-                for k, b in (("col", self.col), ("prev", self.prev), ("next", self.nxt))}
+        """Per bundle: the row block of the static ray buffers' gradient that belongs to it (one leaf per field for all bundles)."""
+        out, lo = {}, 0
+        for k, b in (("col", self.col), ("prev", self.prev), ("next", self.nxt)):
+            if b is None:
+                out[k] = None
+                continue
+            hi = lo + len(b)
+            if not _leaf(b.origins).requires_grad:
+                out[k] = None
+            else:
+                go, gd = _leaf(b.origins).grad, _leaf(b.directions).grad
+                whole = b.origins._base is None
+                out[k] = (go if whole else go[lo:hi], gd if whole else gd[lo:hi]) if go is not None else None
+            lo = hi
+        return out
 
     @property
     def ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
@@ -244,24 +313,31 @@ class GraphedTrainStep:
                  next_jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
         if (next_bundles is not None or next_jitter is not None) and not self.prefetch:
             raise ValueError("next_bundles / next_jitter belong to a step built with prefetch_march=True")
-        _copy_bundle(self.col, col)
-        _copy_bundle(self.prev, prev)
-        _copy_bundle(self.nxt, nxt)
-        with torch.no_grad():
-            for k, v in self.batch.items():
-                if isinstance(v, dict):
-                    for kk, vv in v.items():
-                        if torch.is_tensor(vv):
-                            vv.copy_(batch[k][kk], non_blocking=True)
-                elif torch.is_tensor(v):
-                    v.copy_(batch[k], non_blocking=True)
-            if self.jitter is not None:
-                if jitter is None:
+        pairs: list = []
+        _copy_pairs(self.col, col, pairs)
+        _copy_pairs(self.prev, prev, pairs)
+        _copy_pairs(self.nxt, nxt, pairs)
+        for k, v in self.batch.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    if torch.is_tensor(vv):
+                        pairs.append((vv, batch[k][kk]))
+            elif torch.is_tensor(v):
+                pairs.append((v, batch[k]))
+        if self.jitter is not None:
+            if jitter is None:
+                with torch.no_grad():
                     self.jitter.uniform_()
-                else:
-                    self.jitter.copy_(jitter, non_blocking=True)
-            elif jitter is not None:
-                raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
+            else:
+                pairs.append((self.jitter, jitter))
+        elif jitter is not None:
+            raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
+        if self.prefetch and next_bundles is not None:       # the announced rays travel with the same launches
+            for dst, src in zip((self.next_col, self.next_prev, self.next_nxt), next_bundles):
+                _copy_pairs(dst, src, pairs)
+            if self.next_jitter is not None and next_jitter is not None:
+                pairs.append((self.next_jitter, next_jitter))
+        _run_copies(pairs)
         if self.prefetch:
             # the samples marched ahead belong to the rays that were ANNOUNCED: if the rays given now are not those very tensors,
             # unmodified (same storage, same version counters; jitter likewise), the samples are dropped and these rays marched
@@ -292,15 +368,11 @@ class GraphedTrainStep:
             # nothing was marched ahead for these rays, or the grid has been refreshed since: march them now (eagerly, same stream)
             with torch.no_grad():
                 self.model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter, out=self._pm[x])
-        if next_bundles is not None:
-            for dst, src in zip((self.next_col, self.next_prev, self.next_nxt), next_bundles):
-                _copy_bundle(dst, src)
+        if next_bundles is not None:         # (the announced rays themselves were copied in by __call__, with this step's inputs)
             if self.next_jitter is not None:
-                with torch.no_grad():
-                    if next_jitter is None:
+                if next_jitter is None:
+                    with torch.no_grad():
                         self.next_jitter.uniform_()
-                    else:
-                        self.next_jitter.copy_(next_jitter, non_blocking=True)
             elif next_jitter is not None:
                 raise ValueError('this step draws its jitter inside the graph; build it with jitter="input" to pass one')
         version = est.grid_version                 # (the grid cannot change while the replay runs: refreshes are eager, in order)

@@ -646,7 +646,7 @@ class LSENeRFModel(nn.Module):
             hi = lo + len(b)
             out_dict[k] = {key: val[lo:hi] for key, val in raw.items()}
             lo = hi
-        loss_dict = self.fused_loss_dict(out_dict, batch)
+        loss_dict = self.fused_loss_dict(out_dict, batch, packed_rgb=raw["rgb"])
         metrics_dict: Dict[str, object] = {}
         if with_metrics and out_dict["col_out"] is not None:
             with torch.no_grad():
@@ -687,13 +687,30 @@ class LSENeRFModel(nn.Module):
         coeff = lambda m: m.pow_coeff if isinstance(m, Powpow) else None
         return fields, coeff(plan["rgb_mapper"]), coeff(plan["ev_mapper"]), (od.weights if isinstance(od, ThreeToOne) else None)
 
-    def fused_loss_dict(self, raw_outputs: Dict[str, Optional[Dict[str, Tensor]]], batch) -> Dict[str, Tensor]:
+    def fused_loss_dict(self, raw_outputs: Dict[str, Optional[Dict[str, Tensor]]], batch,
+                        packed_rgb: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """Training losses straight from the three bundles' ``exec_get_outputs`` results ({"col_out", "prev_out", "next_out"},
         each the raw render or None): routing, mappers, deblur mean and both MSEs run in one forward and one backward launch.
-        Same values as ``get_loss_dict`` over ``route_outputs`` (tests/test_gpu_configs.py)."""
+        Same values as ``get_loss_dict`` over ``route_outputs`` (tests/test_gpu_configs.py).
+        ``packed_rgb``: the render of ONE packed pass whose row blocks [colour | previous | next] the three entries of
+        ``raw_outputs`` are (train_step_bundles): the epilogue then works on that buffer directly and its backward returns one
+        gradient buffer instead of three slices to be scattered back."""
         assert self.training, "the fused epilogue is the training-mode routing"
         desc = self._epilogue_desc()
         col, prev, nxt = (raw_outputs.get(k) for k in ("col_out", "prev_out", "next_out"))
+        if desc is not None and packed_rgb is not None:
+            fields, pow_rgb, pow_evs, w31 = desc
+            n_col = col["rgb"].shape[0] if col is not None else 0
+            n_ev = prev["rgb"].shape[0] if prev is not None else 0
+            rgb_loss, event_loss = ops.loss_epilogue_packed(
+                fields, packed_rgb, n_col, n_ev, batch["col_batch"]["image"] if col is not None else None,
+                batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31)
+            losses = {}
+            if col is not None:
+                losses["rgb_loss"] = rgb_loss
+            if prev is not None:
+                losses["event_loss"] = event_loss
+            return losses
         if desc is None:
             routed = {k: (self.route_outputs(v, None, ev_out=(k != "col_out")) if v is not None else None)
                       for k, v in (("col_out", col), ("prev_out", prev), ("next_out", nxt))}

@@ -977,6 +977,66 @@ class _LossEpilogueFn(torch.autograd.Function):
                 d_sc[2:5].view_as(w31) if w31 is not None else None)
 
 
+class _LossEpiloguePackedFn(torch.autograd.Function):
+    """``_LossEpilogueFn`` on the render of ONE packed pass: ``rgb_all`` [n_col_rays + 2 n_ev, 3] holds the colour, previous-event and
+    next-event bundles' rows one after the other (LSENeRFModel.train_step_bundles).  The three parts are handed to the kernels as
+    pointers into that one buffer, and the backward fills ONE gradient buffer -- the per-bundle slices of the generic route cost, in
+    backward, a zero-fill + a copy per bundle and two adds (eight ~5 us launches per step in the rocprofv3 timeline of a replayed
+    3-bundle step, tools/graph_timeline.py)."""
+
+    @staticmethod
+    def forward(ctx, desc_fields, rgb_all, n_col_rays, n_ev, col_gt, evs_gt, pow_rgb, pow_evs, w31):
+        dev = rgb_all.device
+        desc = _lib.EpilogueDesc(*desc_fields)
+        group = desc.deblur_group
+        if n_col_rays % group != 0 or (n_col_rays and col_gt.shape[0] != n_col_rays // group):
+            raise ValueError(f"colour bundle of {n_col_rays} rays does not split into groups of {group} for "
+                             f"{0 if col_gt is None else col_gt.shape[0]} targets")
+        if rgb_all.shape[0] != n_col_rays + 2 * n_ev:
+            raise ValueError(f"packed render of {rgb_all.shape[0]} rays for {n_col_rays} colour + 2 x {n_ev} event rays")
+        col = rgb_all[:n_col_rays] if n_col_rays else None
+        prev = rgb_all[n_col_rays:n_col_rays + n_ev] if n_ev else None
+        nxt = rgb_all[n_col_rays + n_ev:] if n_ev else None
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col, "col_rgb", True), _f32(col_gt, "col_gt", True),
+                  n_col_rays // group, _f32(prev, "prev_rgb", True), _f32(nxt, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
+                  n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  ctypes.c_void_p(losses.data_ptr()), _stream())
+        ctx.save_for_backward(rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31)
+        ctx.desc_fields, ctx.n_col_rays, ctx.n_ev = desc_fields, n_col_rays, n_ev
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_evs):
+        rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31 = ctx.saved_tensors
+        dev = rgb_all.device
+        desc = _lib.EpilogueDesc(*ctx.desc_fields)
+        n0, ne = ctx.n_col_rays, ctx.n_ev
+        g_rgb = g_rgb.reshape(1).contiguous().float() if g_rgb is not None else None
+        g_evs = g_evs.reshape(1).contiguous().float() if g_evs is not None else None
+        d_all = torch.empty_like(rgb_all)          # every row belongs to exactly one part, and the kernel overwrites its parts
+        part = lambda t, a, b: (t[a:b] if b > a else None)
+        _lib.call("lse_loss_epilogue_bwd", ctypes.byref(desc), _f32(part(rgb_all, 0, n0), "col_rgb", True), _f32(col_gt, "col_gt", True),
+                  n0 // desc.deblur_group, _f32(part(rgb_all, n0, n0 + ne), "prev_rgb", True),
+                  _f32(part(rgb_all, n0 + ne, n0 + 2 * ne), "next_rgb", True), _f32(evs_gt, "evs_gt", True), ne,
+                  _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(part(d_all, 0, n0), "d_col", True),
+                  _f32(part(d_all, n0, n0 + ne), "d_prev", True), _f32(part(d_all, n0 + ne, n0 + 2 * ne), "d_next", True),
+                  ctypes.c_void_p((d_sc := torch.empty(5, dtype=torch.float32, device=dev)).data_ptr()), _stream())
+        return (None, d_all, None, None, None, None,
+                d_sc[0:1].view_as(pow_rgb) if pow_rgb is not None else None,
+                d_sc[1:2].view_as(pow_evs) if pow_evs is not None else None,
+                d_sc[2:5].view_as(w31) if w31 is not None else None)
+
+
+def loss_epilogue_packed(desc_fields: tuple, rgb_all, n_col_rays: int, n_ev: int, col_gt, evs_gt, pow_rgb=None, pow_evs=None, w31=None):
+    """``loss_epilogue`` for the bundles of one packed pass, given as row blocks [colour | previous | next] of ONE render."""
+    c = lambda t: _c(t.float()) if t is not None else None
+    return _LossEpiloguePackedFn.apply(tuple(desc_fields), c(rgb_all), int(n_col_rays), int(n_ev), c(col_gt),
+                                       c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31)
+
+
 def loss_epilogue(desc_fields: tuple, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb=None, pow_evs=None, w31=None):
     """Routing + intensity mappers + rgb MSE + log-intensity event MSE in one launch (lse_loss_epilogue_fwd).
     ``desc_fields`` = (rgb_mapped, rgb_mapper, evs_mapper, ev_one_dim, deblur_group, evs_loss_weight).

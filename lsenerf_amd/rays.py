@@ -53,20 +53,40 @@ class RayBundle:
         if len(bundles) == 1:
             return bundles[0]
 
+        def join_vals(vals):
+            base = _whole_base(vals)       # the parts ARE one tensor cut into consecutive row blocks: no copy, no autograd node
+            return base if base is not None else torch.cat(vals, dim=0)
+
         def join(name):
             vals = [getattr(b, name) for b in bundles]
             if all(v is None for v in vals):
                 return None
             if any(v is None for v in vals):
                 raise ValueError(f"RayBundle.cat: '{name}' is set on some bundles only")
-            return torch.cat(vals, dim=0)
+            return join_vals(vals)
         keys = set(bundles[0].metadata)
         if any(set(b.metadata) != keys for b in bundles):
             raise ValueError("RayBundle.cat: metadata keys differ between bundles")
-        meta = {k: torch.cat([b.metadata[k] for b in bundles], dim=0) for k in keys}
+        meta = {k: join_vals([b.metadata[k] for b in bundles]) for k in keys}
         return RayBundle(origins=join("origins"), directions=join("directions"), pixel_area=join("pixel_area"),
                          camera_indices=join("camera_indices"), nears=join("nears"), fars=join("fars"), times=join("times"),
                          metadata=meta)
+
+
+def _whole_base(vals):
+    """If ``vals`` are consecutive dim-0 slices of ONE contiguous tensor that together cover it, that tensor; else None.
+    (lsenerf_amd.graph keeps the static inputs of a captured step that way: the three bundles of a step are row blocks of one buffer
+    per field, so joining them costs no kernel -- and, for rays that carry gradients, the joined tensor is the leaf itself.)"""
+    base = vals[0]._base
+    if base is None or not base.is_contiguous() or any(v._base is not base for v in vals):
+        return None
+    expect = base.storage_offset()
+    for v in vals:
+        if v.dim() != base.dim() or v.shape[1:] != base.shape[1:] or v.dtype != base.dtype or not v.is_contiguous() \
+                or v.storage_offset() != expect:
+            return None
+        expect += v.numel()
+    return base if expect == base.storage_offset() + base.numel() else None
 
 
 @dataclass
