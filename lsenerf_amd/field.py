@@ -192,7 +192,14 @@ class GlobalEmbedding(EvsFrameEmbedding):
         super().__init__(config, 1, num_dims)
 
     def ray_indices(self, ray_bundle_metadata, camera_indices, n_rays, device) -> Tensor:
-        return torch.zeros(n_rays, dtype=torch.int32, device=device)
+        # every ray reads row 0: one zero vector per (count, device), kept (a fresh torch.zeros is a ~6 us fill per step; never
+        # created inside a graph capture, whose allocations belong to the graph's pool)
+        z = self.__dict__.get("_zero_idx")
+        if z is None or z.shape[0] != n_rays or z.device != torch.device(device):
+            z = torch.zeros(n_rays, dtype=torch.int32, device=device)
+            if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self.__dict__["_zero_idx"] = z
+        return z
 
     def forward(self, x: RaySamples, call_from_test=False):
         idxs = x.camera_indices * 0

@@ -320,7 +320,7 @@ def ray_planes(n_rays: int, device, near_plane: float, far_plane: float, t_min=N
 def pack_info_from_counts(cnts: torch.Tensor):
     R = cnts.shape[0]
     packed = torch.empty((R, 2), dtype=torch.int64, device=cnts.device)
-    total = torch.zeros(1, dtype=torch.int64, device=cnts.device)
+    total = torch.empty(1, dtype=torch.int64, device=cnts.device)       # written (not accumulated) by the kernel, also for R == 0
     _lib.call("lse_pack_info_from_counts", _chk(cnts, torch.int64, "cnts"), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
     return packed, total
