@@ -162,10 +162,12 @@ class GraphedTrainStep:
             losses = step(col_it, prev_it, nxt_it, batch_it)             # {"rgb_loss", "event_loss"}: device scalars
             # step.ray_grads: gradients w.r.t. the rays of this step (per bundle), for a pose optimiser outside the graph
 
-    Build it before, or well after, eager steps of the SAME model: a loss tensor of an earlier eager step that is still alive keeps
-    its autograd graph and the AccumulateGrad nodes of the small torch-side parameters (mapper scalars), which stay bound to the
-    stream they were created on; a capture whose backward runs through such a node leaves the capturing stream (torch warns, the HIP
-    runtime may crash in hipStreamEndCapture).  ``del`` the old losses / outputs first.
+    Earlier EAGER steps of the same model whose losses / outputs are still alive keep their autograd graphs and with them the
+    parameters' AccumulateGrad nodes, bound to the stream they were created on; a capture whose backward EXECUTES such a node leaves
+    the capturing stream (torch warns, the HIP runtime crashed in hipStreamEndCapture).  The step itself runs none: every parameter
+    of the fast path receives its gradient directly (the hash table, the MLPs, the embedding, and since round 4 the loss epilogue's
+    scalars: ops._scalar_param_grads; tests/test_gpu_graph.py runs the situation in a child process).  Parameters that only the
+    torch route updates (the MLP intensity mappers) still go through AccumulateGrad: with those, ``del`` old losses first.
 
     ``ray_grads=True`` makes the static ray tensors leaves that require gradients (BASELINE config 4: BAD-NeRF pose
     optimisation); their ``.grad`` after a replay is the gradient of the summed loss w.r.t. the rays that were copied in.

@@ -971,10 +971,29 @@ class _LossEpilogueFn(torch.autograd.Function):
                   ctx.n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(d_col, "d_col", True),
                   _f32(d_prev, "d_prev", True), _f32(d_next, "d_next", True), ctypes.c_void_p(d_sc.data_ptr()), _stream())
-        return (None, d_col, None, d_prev, d_next, None,
-                d_sc[0:1].view_as(pow_rgb) if pow_rgb is not None else None,
-                d_sc[1:2].view_as(pow_evs) if pow_evs is not None else None,
-                d_sc[2:5].view_as(w31) if w31 is not None else None)
+        return (None, d_col, None, d_prev, d_next, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31)
+
+
+def _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31):
+    """Gradients of the epilogue's three scalar parameters (d_sc = [d pow_rgb, d pow_evs, d w31[3]]).  A parameter whose .grad is
+    already allocated (optim.FlatParams: a view of the flat gradient buffer) is accumulated into HERE and the Function returns None
+    for it, like the big parameters (_direct_grad): the step then runs no AccumulateGrad node of a model parameter at all.  That is
+    what makes a captured step indifferent to EARLIER eager graphs of the same model that are still alive -- they keep the
+    parameters' AccumulateGrad nodes alive, bound to the stream they were created on, and a capture whose backward executed such a
+    node left the capturing stream (torch warns; the HIP runtime crashed in hipStreamEndCapture, round 4)."""
+    out = []
+    for p, lo, hi in ((pow_rgb, 0, 1), (pow_evs, 1, 2), (w31, 2, 5)):
+        if p is None:
+            out.append(None)
+            continue
+        g = d_sc[lo:hi].view_as(p)
+        direct = _direct_grad(p)
+        if direct is not None:
+            direct.add_(g)
+            out.append(None)
+        else:
+            out.append(g)
+    return tuple(out)
 
 
 class _LossEpiloguePackedFn(torch.autograd.Function):
@@ -1024,10 +1043,7 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(part(d_all, 0, n0), "d_col", True),
                   _f32(part(d_all, n0, n0 + ne), "d_prev", True), _f32(part(d_all, n0 + ne, n0 + 2 * ne), "d_next", True),
                   ctypes.c_void_p((d_sc := torch.empty(5, dtype=torch.float32, device=dev)).data_ptr()), _stream())
-        return (None, d_all, None, None, None, None,
-                d_sc[0:1].view_as(pow_rgb) if pow_rgb is not None else None,
-                d_sc[1:2].view_as(pow_evs) if pow_evs is not None else None,
-                d_sc[2:5].view_as(w31) if w31 is not None else None)
+        return (None, d_all, None, None, None, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31)
 
 
 def loss_epilogue_packed(desc_fields: tuple, rgb_all, n_col_rays: int, n_ev: int, col_gt, evs_gt, pow_rgb=None, pow_evs=None, w31=None):

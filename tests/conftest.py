@@ -100,8 +100,35 @@ def _launch_dp_rehearsal(config, backend="gloo"):
     return res
 
 
+def _test_file_selected(config, fname: str, kw_token: str) -> bool:
+    kw = config.getoption("keyword", "") or ""
+    if kw and kw_token not in kw:
+        return False
+    files = [a.split("::")[0] for a in config.args]
+    return (not files) or any(os.path.basename(os.path.normpath(a)) == fname or os.path.isdir(a) for a in files)
+
+
+def _launch_capture_probe(config):
+    """tools/capture_after_eager_probe.py as a fresh child process, BEFORE this process touches the GPU: it captures a training step
+    while earlier eager losses of the same model are still alive -- the situation that crashed the HIP runtime in
+    hipStreamEndCapture in round 4.  A regression is a segfault, so it must not run inside the pytest process."""
+    import torch
+    if torch.cuda.device_count() < 1:
+        return {"launched": False, "reason": "no GPU visible"}
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_after_eager_probe.py")], cwd=ROOT, capture_output=True,
+                           text=True, timeout=420)
+        return {"launched": True, "returncode": p.returncode, "log_tail": (p.stdout + p.stderr)[-3000:]}
+    except subprocess.TimeoutExpired as e:
+        return {"launched": True, "returncode": -9, "log_tail": f"timeout: {e}"}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if _gpu_tier_selected(config) and _test_file_selected(config, "test_gpu_graph.py", "graph"):
+        config._lse_capture_probe = _launch_capture_probe(config)
+    else:
+        config._lse_capture_probe = {"launched": False, "reason": "tests/test_gpu_graph.py not selected"}
     # the outcome of the 2-rank data-parallel rehearsal of the HIP model (tools/dp_rehearsal.py); tests/test_gpu_dp.py asserts on it
     if not _gpu_tier_selected(config):
         config._lse_dp_rehearsal = config._lse_rccl_rehearsal = {"launched": False, "reason": "GPU tier not selected"}
@@ -121,6 +148,11 @@ def dp_rehearsal(request):
 @pytest.fixture(scope="session")
 def rccl_rehearsal(request):
     return request.config._lse_rccl_rehearsal
+
+
+@pytest.fixture(scope="session")
+def capture_probe(request):
+    return request.config._lse_capture_probe
 
 
 def pytest_collection_modifyitems(config, items):

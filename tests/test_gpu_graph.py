@@ -318,3 +318,17 @@ def test_replays_issued_far_ahead_of_the_device_take_their_own_steps_scalars():
         want = (lr, 1 - 0.9 ** t, 1 / math.sqrt(1 - 0.999 ** t))
         for a, b in zip(got[i].tolist(), want):
             assert abs(a - b) <= 2e-7 * abs(b), (i, got[i].tolist(), want)
+
+
+def test_capturing_a_step_survives_earlier_eager_graphs_of_the_same_model(capture_probe):
+    """Eager losses that are still alive keep their autograd graph and the parameters' AccumulateGrad nodes, bound to the stream they
+    were created on.  Until round 4 a capture whose backward executed such a node (the loss epilogue's scalar parameters) crashed the
+    HIP runtime in hipStreamEndCapture.  Those gradients are now accumulated directly (ops._scalar_param_grads), like the big
+    parameters: no AccumulateGrad node of a model parameter runs inside a step.  The probe runs as a child process started by
+    tests/conftest.py before this process touched the GPU (a regression is a segfault): two eager steps with retained graphs, then
+    capture + replay, for the cfg 2 and cfg 3 compositions at full size."""
+    if not capture_probe.get("launched"):
+        pytest.skip(capture_probe.get("reason", "probe not launched"))
+    assert capture_probe["returncode"] == 0, capture_probe["log_tail"]
+    assert "cfg2 captured and replayed with 2 eager graphs alive" in capture_probe["log_tail"]
+    assert "cfg3 captured and replayed with 2 eager graphs alive" in capture_probe["log_tail"]

@@ -7,6 +7,19 @@ of its kernels.
 import csv, glob, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
+if sys.argv[1] == "run_headline":      # the eager M-march step bench.py's `value` is measured on
+    import torch
+    import bench
+    from lsenerf_amd.optim import FlatAdam, FlatParams
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model, rb, target, jitter = bench.build_workload(dev, 1000)
+    opt = FlatAdam(FlatParams(model.get_param_groups()["fields"]), lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
+    for _ in range(12):
+        bench.train_step(model, rb, target, jitter, opt, 1)
+    torch.cuda.synchronize()
+    sys.exit(0)
+
 if sys.argv[1] == "run":
     import torch
     import bench
@@ -46,7 +59,9 @@ def step_between(i0, i1, title):
     say(f"   sum of kernel durations {busy / 1e3:.1f} us, sum of positive gaps {gaps / 1e3:.1f} us")
 n = len(adam)
 # blocks: ... the last 9 Adam launches belong to the prefetched timing (3 warm-up + 6 timed), the 9 before to the plain graphed timing
-if n >= 20:
+if sys.argv[1] == "analyse_headline":
+    step_between(adam[-3], adam[-2], "eager M-march step (bench.py headline)")
+elif n >= 20:
     step_between(adam[-14], adam[-13], "plain graphed replay")
     step_between(adam[-3], adam[-2], "replay with the next step's marcher on a side stream")
 if len(sys.argv) > 3:
