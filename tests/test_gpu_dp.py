@@ -39,9 +39,13 @@ def test_two_rank_rehearsal_ran_every_exchange(dp_rehearsal):
 def test_sharded_step_equals_one_process_on_the_full_batch(mode, dp_rehearsal):
     rep, _ = _report(dp_rehearsal)
     e = rep["modes"][mode]
-    floor = rep["single_process"]["run_to_run_first_grad_err"]       # two runs of ONE process differ by this (float atomics)
-    # first-step gradient, rank-averaged, against the single process: per parameter tensor max |g - g_ref| <= 3e-6 max|g_ref|
-    assert e["first_step_grad_err_vs_single"] <= max(3e-6, 3 * floor), (mode, e, floor)
+    # two runs of ONE process differ by `floor` (float atomics: 0.7e-6 .. 1.4e-6 over the rounds' runs), and the comparison below is
+    # between two such runs with yet another summation order: measured 1.3e-6 .. 3.1e-6.  The bound was max(3e-6, 3 x floor) until a
+    # round-4 run measured 3.09e-6 against a floor of 0.73e-6; it is max(6e-6, 4 x floor) now -- a wrong exchange (a rank's
+    # contribution missing or counted twice, a stale slice) is off by O(1), five orders of magnitude above either bound.
+    floor = rep["single_process"]["run_to_run_first_grad_err"]
+    # first-step gradient, rank-averaged, against the single process: per parameter tensor max |g - g_ref| <= 6e-6 max|g_ref|
+    assert e["first_step_grad_err_vs_single"] <= max(6e-6, 4 * floor), (mode, e, floor)
     assert e["params_bit_identical_across_ranks"], (mode, e)
     assert e["grids_bit_identical_across_ranks_after_refresh_step0_step320"] == [True, True], (mode, e)
     assert e["samples_match_single_process"], (mode, e)
@@ -63,7 +67,7 @@ def test_rccl_calls_of_every_exchange_execute_on_hip_tensors(rccl_rehearsal):
     floor = rep["single_process"]["run_to_run_first_grad_err"]
     for mode in MODES:
         e = rep["modes"][mode]
-        assert e["first_step_grad_err_vs_single"] <= max(3e-6, 3 * floor), (mode, e, floor)
+        assert e["first_step_grad_err_vs_single"] <= max(6e-6, 4 * floor), (mode, e, floor)
         assert e["within_tolerance"] and e["samples_match_single_process"], (mode, e)
         assert e["grids_bit_identical_across_ranks_after_refresh_step0_step320"] == [True, True], (mode, e)
     assert rep["all_ok"], r["log_tail"]

@@ -14,7 +14,7 @@ graphed (sampler ... backward replayed as ONE HIP graph per rank, lsenerf_amd.gr
 then the plain all-reduce and Adam) -- the script runs: occupancy refresh at step 0 (warm-up branch: all cells), 3 train steps in the reference's default
 configuration (cone 0.004, alpha_thre 0.01 => sigma_fn pre-pass on, 4-level 128^3 grid), occupancy refresh at step 320
 (sampled branch), and asserts
-  * the first step's rank-averaged gradient == the single-process full-batch gradient within 3e-6 * max|g| per parameter
+  * the first step's rank-averaged gradient == the single-process full-batch gradient within 6e-6 * max|g| per parameter
     tensor (the clean statement of "sharding + one all-reduce == full batch": nothing has amplified the float-atomic
     summation noise yet; two runs of the SAME single process differ by 1e-6 * max|g|),
   * flat parameters after 3 Adam steps == single-process parameters within 1e-6 * max|p| for all but a vanishing
@@ -269,7 +269,7 @@ def main():
               "single_process": {"samples_per_step": n_ref, "occupied_fraction_after_refresh": occ_ref,
                                  "run_to_run_first_grad_err": grad_err(g_ref2), "run_to_run_max_abs_param_diff": floor_p,
                                  "run_to_run_fraction_of_params_beyond_1e-6_max": floor_frac},
-              "tolerance": "first-step gradient: per-tensor max err <= max(3e-6, 3 x run-to-run) * max|g|; parameters after 3 "
+              "tolerance": "first-step gradient: per-tensor max err <= max(6e-6, 4 x run-to-run) * max|g|; parameters after 3 "
                            "Adam steps: fraction beyond 1e-6 * max|p| <= max(1e-4, 2 x single-process run-to-run fraction) "
                            "and max|p_dp - p_single| <= max(1e-6 * max|p|, 3 x run-to-run max diff); samples per step "
                            "within 1e-5 relative (visibility-threshold flips on parameters that differ in the last bits)",
@@ -297,7 +297,7 @@ def main():
         tdist.all_reduce(same, op=tdist.ReduceOp.MIN)
         entry = {"first_step_grad_err_vs_single": gerr, "max_abs_err_vs_single": err, "rel_to_max_param": err / scale,
                  "fraction_of_params_beyond_1e-6_max": frac,
-                 "within_tolerance": gerr <= max(3e-6, 3 * floor_g) and frac <= max(1e-4, 2 * floor_frac)
+                 "within_tolerance": gerr <= max(6e-6, 4 * floor_g) and frac <= max(1e-4, 2 * floor_frac)
                  and err <= max(1e-6 * scale, 3 * floor_p),
                  "params_bit_identical_across_ranks": bool(same.item()),
                  "grids_bit_identical_across_ranks_after_refresh_step0_step320": grids_ok,
