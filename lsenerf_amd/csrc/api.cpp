@@ -21,6 +21,7 @@ struct Option { const char *name; std::atomic<int64_t> value; };
 static Option g_options[] = {
     {"hash_fwd_mapping", {4}},
     {"hash_fwd_lds_levels", {0}},
+    {"compact_features_groups", {4}},
     {"mlp_fwd_cfg", {28}},
     {"mlp_bwd_cfg", {28}},
     {"mlp_bwd_impl", {1}},

@@ -251,9 +251,16 @@ __global__ __launch_bounds__(256) void compact_features_kernel(const uint8_t *__
                                                                int64_t n_new, float *__restrict__ o_x01,
                                                                uint8_t *__restrict__ o_sel, float2 *__restrict__ o_y)
 {
+    // blockIdx.y = level group: one wave per (ray, group of levels).  A wave per RAY alone is 3.4 waves per SIMD at 3510 rays, each
+    // walking its ray's candidates 64 at a time with dependent trips to memory -- latency-bound at 3.4 TB/s; with the levels split over
+    // gridDim.y groups (every group recomputes the cheap ballot / popcount positions; group 0 also moves x01 and the selector) the
+    // same bytes move with gridDim.y times the waves in flight.
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     const int lane = threadIdx.x & 63;
+    const int per = (n_levels + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int l_lo = (int)blockIdx.y * per, l_hi = min(n_levels, l_lo + per);
+    const bool first = blockIdx.y == 0;
     const int64_t s0 = packed[2 * ray], cnt = packed[2 * ray + 1];
     int64_t dst = new_packed[2 * ray];
     for (int64_t base = 0; base < cnt; base += 64) {
@@ -262,19 +269,21 @@ __global__ __launch_bounds__(256) void compact_features_kernel(const uint8_t *__
         const unsigned long long bal = __ballot(keep);
         const int64_t o = dst + __popcll(bal & ((1ull << lane) - 1ull));
         if (keep) {
-            o_x01[o * 3 + 0] = x01[i * 3 + 0];
-            o_x01[o * 3 + 1] = x01[i * 3 + 1];
-            o_x01[o * 3 + 2] = x01[i * 3 + 2];
-            o_sel[o] = sel[i];
-            int l = 0;
-            for (; l + 8 <= n_levels; l += 8) {        // 8 independent loads in flight, then 8 stores
-                float2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = y[(int64_t)(l + u) * n_old + i];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) o_y[(int64_t)(l + u) * n_new + o] = v[u];
+            if (first) {
+                o_x01[o * 3 + 0] = x01[i * 3 + 0];
+                o_x01[o * 3 + 1] = x01[i * 3 + 1];
+                o_x01[o * 3 + 2] = x01[i * 3 + 2];
+                o_sel[o] = sel[i];
             }
-            for (; l < n_levels; ++l) o_y[(int64_t)l * n_new + o] = y[(int64_t)l * n_old + i];
+            int l = l_lo;
+            for (; l + 4 <= l_hi; l += 4) {        // 4 independent loads in flight, then 4 stores
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = y[(int64_t)(l + u) * n_old + i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o_y[(int64_t)(l + u) * n_new + o] = v[u];
+            }
+            for (; l < l_hi; ++l) o_y[(int64_t)l * n_new + o] = y[(int64_t)l * n_old + i];
         }
         dst += __popcll(bal);
     }
@@ -291,7 +300,8 @@ extern "C" int lse_compact_features(const uint8_t *mask, const int64_t *packed_i
     if (n_rays == 0 || n_new == 0) return LSE_OK;
     LSE_REQUIRE(mask && packed_info && new_packed_info && x01 && selector && y && out_x01 && out_selector && out_y,
                 "lse_compact_features: null pointer");
-    hipLaunchKernelGGL(compact_features_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, lse::as_stream(stream), mask, packed_info,
+    const int groups = (int)std::min<int64_t>(std::max<int64_t>(lse::option("compact_features_groups"), 1), n_levels);
+    hipLaunchKernelGGL(compact_features_kernel, dim3((n_rays + 3) / 4, groups), dim3(256), 0, lse::as_stream(stream), mask, packed_info,
                        new_packed_info, n_rays, x01, selector, reinterpret_cast<const float2 *>(y), n_levels, n_old, n_new,
                        out_x01, out_selector, reinterpret_cast<float2 *>(out_y));
     return lse::check_launch("lse_compact_features");

@@ -1162,3 +1162,33 @@ def test_mlp_full_size_properties(shape):
     _, dp2, _, _ = run(0, N, g2)
     _, dp12, _, _ = run(0, N, g1 - 2.0 * g2)
     assert nmax_err(dp12, dp - 2.0 * dp2, 1e-12) < TOL_GRAD
+
+
+def test_compact_features_equals_boolean_indexing_for_every_level_grouping():
+    """lse_compact_features (survivors of the visibility pre-pass keep their positions, selector and level-major hash features) against
+    torch boolean indexing, with the levels split over 1 .. 16 groups of waves per ray (option compact_features_groups; default 4),
+    level counts that do not divide evenly, rays without candidates and rays without survivors."""
+    from lsenerf_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    try:
+        for L, R in ((16, 257), (5, 33), (1, 7)):
+            cnt = torch.randint(0, 200, (R,), device="cuda", generator=g)
+            cnt[::7] = 0                                                      # rays that missed every occupied cell
+            packed = torch.stack([torch.cumsum(cnt, 0) - cnt, cnt], -1).contiguous()
+            N = int(cnt.sum())
+            keep = torch.rand(N, device="cuda", generator=g) < 0.6
+            seg = torch.repeat_interleave(torch.arange(R, device="cuda"), cnt)
+            keep[seg % 5 == 1] = False                                        # rays whose candidates are all culled
+            new_cnt = torch.zeros(R, dtype=torch.long, device="cuda").index_add_(0, seg, keep.long())
+            new_packed = torch.stack([torch.cumsum(new_cnt, 0) - new_cnt, new_cnt], -1).contiguous()
+            n_new = int(new_cnt.sum())
+            x01 = torch.rand(N, 3, device="cuda", generator=g)
+            sel = (torch.rand(N, device="cuda", generator=g) < 0.9).to(torch.uint8)
+            y = torch.randn(L, N, 2, device="cuda", generator=g)
+            for groups in (1, 2, 3, 4, 16):
+                _lib.set_option("compact_features_groups", groups)
+                ox, os_, oy = ops.compact_features(keep.to(torch.uint8).contiguous(), packed, new_packed, n_new, x01, sel, y)
+                assert torch.equal(ox, x01[keep]) and torch.equal(os_, sel[keep]) and torch.equal(oy, y[:, keep]), (L, R, groups)
+    finally:
+        _lib.set_option("compact_features_groups", 4)
