@@ -478,7 +478,7 @@ class _HashFn(torch.autograd.Function):
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
         opts = hash_bwd_opts_with_workspace(desc, x01.device)     # defaults + the coarse-level replica workspace
-        hooks = _HASH_BWD_HOOKS.get(table.data_ptr())      # per TABLE, not per process: other models in the process are untouched
+        hooks = _hash_bwd_hooks_of(table)      # per TABLE, not per process: other models in the process are untouched
         split = hooks.get("split") if hooks else None
         if hooks and hooks.get("before") is not None:     # e.g. fork a side stream here: the scatter below is the last big kernel of the backward pass
             hooks["before"]()
@@ -622,21 +622,37 @@ class _MlpFn(torch.autograd.Function):
 _HASH_BWD_HOOKS: dict = {}
 
 
+def _hash_bwd_hooks_of(table: torch.Tensor):
+    """The hooks registered for the table stored at ``table``'s address, or None.  An entry whose owner (the tensor object the hooks
+    were installed through) has been collected is dropped: its address may belong to somebody else's table by now."""
+    h = _HASH_BWD_HOOKS.get(table.data_ptr())
+    if h is not None and h["owner"]() is None:
+        _HASH_BWD_HOOKS.pop(table.data_ptr(), None)
+        return None
+    return h
+
+
 def set_hash_bwd_hook(table: torch.Tensor, kind: str, value) -> None:
-    """Install (``value`` not None) or remove a hook of the hash backward of ``table`` (``kind``: "before" | "split")."""
+    """Install (``value`` not None) or remove a hook of the hash backward of ``table`` (``kind``: "before" | "split").  Keyed by
+    the table's storage address as it is NOW: install after optim.FlatParams has re-pointed the parameter into the flat buffer."""
+    import weakref
     assert kind in ("before", "split")
     key = table.data_ptr()
-    h = _HASH_BWD_HOOKS.setdefault(key, {})
+    h = _hash_bwd_hooks_of(table)
     if value is None:
-        h.pop(kind, None)
-        if not h:
-            _HASH_BWD_HOOKS.pop(key, None)
-    else:
-        h[kind] = value
+        if h is not None:
+            h.pop(kind, None)
+            if set(h) == {"owner"}:
+                _HASH_BWD_HOOKS.pop(key, None)
+        return
+    if h is None:
+        h = _HASH_BWD_HOOKS[key] = {"owner": weakref.ref(table)}
+    h[kind] = value
 
 
 def get_hash_bwd_hook(table: torch.Tensor, kind: str):
-    return _HASH_BWD_HOOKS.get(table.data_ptr(), {}).get(kind)
+    h = _hash_bwd_hooks_of(table)
+    return None if h is None else h.get(kind)
 
 
 DIRECT_PARAM_GRADS = True   # backward kernels accumulate into a preallocated leaf .grad (see _direct_grad)

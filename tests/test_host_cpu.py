@@ -379,3 +379,20 @@ def test_raybundle_cat_of_row_blocks_of_one_buffer_is_that_buffer():
         assert r2.origins is not base_o and torch.equal(r2.origins, torch.cat([base_o[a:b] for a, b in sel]))
     mixed = RayBundle.cat([RayBundle(origins=base_o[0:4], directions=base_d[0:4]), RayBundle(origins=torch.zeros(2, 3), directions=torch.zeros(2, 3))])
     assert mixed.origins.shape == (6, 3)
+
+
+def test_hash_bwd_hooks_belong_to_their_table_and_die_with_their_owner():
+    import gc
+    from lsenerf_amd import ops
+    t1, t2 = torch.zeros(64), torch.zeros(64)
+    ops.set_hash_bwd_hook(t1, "before", lambda: None)
+    assert ops.get_hash_bwd_hook(t1, "before") is not None and ops.get_hash_bwd_hook(t2, "before") is None
+    assert ops.get_hash_bwd_hook(t1.view(8, 8), "before") is not None           # looked up by storage address (autograd hands out other objects)
+    ops.set_hash_bwd_hook(t1, "before", None)
+    assert not ops._HASH_BWD_HOOKS
+    owner = t2.view(-1)                     # installed through an object that goes away while the storage lives on
+    ops.set_hash_bwd_hook(owner, "split", (3, lambda: None))
+    assert ops.get_hash_bwd_hook(t2, "split")[0] == 3
+    del owner
+    gc.collect()
+    assert ops.get_hash_bwd_hook(t2, "split") is None and not ops._HASH_BWD_HOOKS
