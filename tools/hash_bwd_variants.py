@@ -40,7 +40,16 @@ def default_config_positions():
                           alpha_thre=0.01, cone_angle=0.004)
     return ops.positions(rb.origins, rb.directions, rs.ray_indices, rs.frustums.starts[..., 0].contiguous(),
                          rs.frustums.ends[..., 0].contiguous(), rs.packed_info, True, None)[0]
-regimes = {"M-march": fixed(o_in, d_in), "M-packed": fixed(o_sp, d_sp), "default": default_config_positions()}
+def headline_positions():
+    """bench.py's headline step (SURVEY 8d exact: sphere rays, one-level grid fully occupied, step chosen for 1024 samples per ray)."""
+    model, rb, _, jitter = bench.build_workload(dev, 1000)
+    cfg = model.config
+    with torch.no_grad():
+        ri, ts, te, packed = model.occupancy_grid.sampling(
+            rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+            render_step_size=cfg.render_step_size, stratified=True, jitter=jitter, return_packed=True)[:4]
+        return ops.positions(rb.origins.detach(), rb.directions.detach(), ri, ts, te, packed, True, None)[0]
+regimes = {"headline": headline_positions(), "M-march(inside box)": fixed(o_in, d_in), "M-packed": fixed(o_sp, d_sp), "default": default_config_positions()}
 variants = sys.argv[1:] or ["impl=1", "impl=2"]
 for name, x01 in regimes.items():
     n = x01.shape[0]
@@ -72,4 +81,4 @@ for name, x01 in regimes.items():
             if rnd: times[v].append(e0.elapsed_time(e1))
     for v, _ in fns:
         t = sorted(times[v])
-        print(f"{name:9s} {v:40s} median {t[len(t)//2]:.3f} ms  min {t[0]:.3f}", flush=True)
+        print(f"{name:20s} {v:40s} median {t[len(t)//2]:.3f} ms  min {t[0]:.3f}", flush=True)
