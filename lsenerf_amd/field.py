@@ -192,14 +192,21 @@ class GlobalEmbedding(EvsFrameEmbedding):
         super().__init__(config, 1, num_dims)
 
     def ray_indices(self, ray_bundle_metadata, camera_indices, n_rays, device) -> Tensor:
-        # every ray reads row 0: one zero vector per (count, device), kept (a fresh torch.zeros is a ~6 us fill per step; never
-        # created inside a graph capture, whose allocations belong to the graph's pool)
-        z = self.__dict__.get("_zero_idx")
-        if z is None or z.shape[0] != n_rays or z.device != torch.device(device):
-            z = torch.zeros(n_rays, dtype=torch.int32, device=device)
-            if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):
-                self.__dict__["_zero_idx"] = z
-        return z
+        # every ray reads row 0: a prefix of one zero vector per device (a fresh torch.zeros is a ~6 us fill per step).  A vector
+        # handed out once is NEVER freed: a captured graph bakes its address into the row-bias / embedding-gradient kernels and
+        # keeps no reference of its own, so a later call with another ray count must not hand that memory back to the allocator
+        # (the next replay would gather and scatter embedding rows through whatever was allocated over it).  Longer requests add a
+        # vector of at least twice the length and keep the old ones (geometric growth: at most 2x the largest request in total).
+        # Never created inside a graph capture, whose allocations belong to the graph's pool.
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else -1)
+        kept = self.__dict__.setdefault("_zero_idx", {}).setdefault((dev.type, index), [])
+        if kept and kept[-1].shape[0] >= n_rays:
+            return kept[-1][:n_rays]
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n_rays, dtype=torch.int32, device=device)
+        kept.append(torch.zeros(max(n_rays, 2 * kept[-1].shape[0] if kept else 0), dtype=torch.int32, device=device))
+        return kept[-1][:n_rays]
 
     def forward(self, x: RaySamples, call_from_test=False):
         idxs = x.camera_indices * 0

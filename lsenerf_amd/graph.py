@@ -41,11 +41,11 @@ from .optim import FlatAdam
 from .rays import RayBundle
 
 
-def _static_bundles(bundles: Sequence[Optional[RayBundle]], requires_grad: bool) -> Tuple[Optional[RayBundle], ...]:
+def _static_bundles(bundles: Sequence[Optional[RayBundle]]) -> Tuple[Optional[RayBundle], ...]:
     """Static copies of the (up to three) bundles of a step whose fields are ROW BLOCKS OF ONE BUFFER PER FIELD: the step joins its
-    bundles into one (RayBundle.cat), and for such parts the join is the buffer itself -- no concatenation kernels inside the graph
-    (four forward, and the split of the ray gradients backward), and with ``requires_grad`` the one leaf per field is that buffer:
-    the ray gradients of all bundles arrive in ``buffer.grad`` (``GraphedTrainStep.ray_grads`` hands out its row blocks)."""
+    bundles into one (``RayBundle.cat(alias_blocks=True)``), and for such parts the join is the buffer itself -- no concatenation
+    kernels inside the graph (four forward, and the split of the ray gradients backward).  The static tensors never require
+    gradients: a step that wants ray gradients runs on FRESH leaves over the same storage (``_fresh_ray_leaves``)."""
     given = [b for b in bundles if b is not None]
     if not given:
         return tuple(None for _ in bundles)
@@ -53,23 +53,29 @@ def _static_bundles(bundles: Sequence[Optional[RayBundle]], requires_grad: bool)
                                       camera_indices=b.camera_indices, nears=b.nears, fars=b.fars, times=b.times,
                                       metadata=dict(b.metadata)) for b in given]) if len(given) > 1 else given[0]
     c = lambda t: None if t is None else t.detach().clone().contiguous()
-    base = RayBundle(origins=c(joined.origins).requires_grad_(requires_grad), directions=c(joined.directions).requires_grad_(requires_grad),
+    base = RayBundle(origins=c(joined.origins), directions=c(joined.directions),
                      pixel_area=c(joined.pixel_area), camera_indices=c(joined.camera_indices), nears=c(joined.nears), fars=c(joined.fars),
                      times=c(joined.times), metadata={k: c(v) for k, v in joined.metadata.items()})
     if len(given) == 1:
         return tuple(base if b is not None else None for b in bundles)
+    return _row_blocks(base, bundles)
+
+
+def _row_blocks(base: RayBundle, bundles: Sequence[Optional[RayBundle]], origins: Optional[Tensor] = None,
+                directions: Optional[Tensor] = None) -> Tuple[Optional[RayBundle], ...]:
+    """``base`` cut into the row blocks of ``bundles`` (plain windows, cut WITHOUT autograd: a view made with grad mode on would own
+    an edge to its buffer's AccumulateGrad node).  ``origins`` / ``directions`` replace the base's ray tensors (fresh leaves)."""
+    o_src = base.origins if origins is None else origins
+    d_src = base.directions if directions is None else directions
     out, lo = [], 0
     for b in bundles:
         if b is None:
             out.append(None)
             continue
         hi = lo + len(b)
-        # the row blocks are plain windows for copying the inputs in: cut WITHOUT autograd -- a view made with grad mode on would own an
-        # edge to its buffer's AccumulateGrad node and keep that node alive from construction on, bound to the construction-time
-        # stream; a capture whose backward runs through it crashes the HIP runtime in hipStreamEndCapture (see the class docstring)
         with torch.no_grad():
             cut = lambda t: None if t is None else t[lo:hi]
-            blk = RayBundle(origins=cut(base.origins), directions=cut(base.directions), pixel_area=cut(base.pixel_area),
+            blk = RayBundle(origins=cut(o_src), directions=cut(d_src), pixel_area=cut(base.pixel_area),
                             camera_indices=cut(base.camera_indices), nears=cut(base.nears), fars=cut(base.fars), times=cut(base.times),
                             metadata={k: cut(v) for k, v in base.metadata.items()})
         out.append(blk)
@@ -78,8 +84,36 @@ def _static_bundles(bundles: Sequence[Optional[RayBundle]], requires_grad: bool)
 
 
 def _leaf(t: Tensor) -> Tensor:
-    """The tensor that owns ``t``'s gradient: ``t`` itself, or the buffer it is a row block of."""
+    """The tensor that owns ``t``'s storage window: ``t`` itself, or the buffer it is a row block of."""
     return t if t._base is None else t._base
+
+
+def _fresh_ray_leaves(statics: Sequence[Optional[RayBundle]]):
+    """The static bundles again, with origins / directions replaced by NEW leaf tensors over the same storage that require
+    gradients: ``(bundles, origins_leaf, directions_leaf)``.
+
+    Why new tensors on every run: a leaf's AccumulateGrad node is created on first use, bound to the stream that is current then,
+    and lives as long as any autograd graph references it.  A leaf that survives from the warm-up runs (or from an earlier capture)
+    carries its node into the capture; if that node's stream is not the capturing stream, torch synchronises the two streams inside
+    the capture ("The AccumulateGrad node's stream does not match ...") -- with the default stream on the other side the HIP runtime
+    crashed in hipStreamEndCapture (round 4).  ``detach()`` costs no kernel, the new leaf has no node yet, so the node of a run is
+    always created by that run, on that run's stream, and dies with that run's graph.  The ray gradients of the captured run land
+    in ``leaf.grad`` -- memory of the graph's private pool, rewritten by every replay, alive as long as the leaf is held."""
+    given = [b for b in statics if b is not None]
+    base_o, base_d = _leaf(given[0].origins), _leaf(given[0].directions)
+    o = base_o.detach().requires_grad_(True)
+    d = base_d.detach().requires_grad_(True)
+    if given[0].origins._base is None:               # one bundle: it IS the buffer
+        b0 = given[0]
+        fresh = RayBundle(origins=o, directions=d, pixel_area=b0.pixel_area, camera_indices=b0.camera_indices, nears=b0.nears,
+                          fars=b0.fars, times=b0.times, metadata=b0.metadata)
+        return tuple(fresh if b is not None else None for b in statics), o, d
+    whole = lambda t: None if t is None else _leaf(t)
+    b0 = given[0]
+    base = RayBundle(origins=base_o, directions=base_d, pixel_area=whole(b0.pixel_area), camera_indices=whole(b0.camera_indices),
+                     nears=whole(b0.nears), fars=whole(b0.fars), times=whole(b0.times),
+                     metadata={k: whole(v) for k, v in b0.metadata.items()})
+    return _row_blocks(base, statics, origins=o, directions=d), o, d
 
 
 def _copy_pairs(dst: Optional[RayBundle], src: Optional[RayBundle], pairs: list) -> None:
@@ -122,15 +156,20 @@ def _run_copies(pairs: list) -> None:
                 d.copy_(s, non_blocking=True)
 
 
-def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool=None):
+def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool=None, stream: Optional[torch.cuda.Stream] = None,
+                 before_capture=None):
     """Capture ``body()`` -- a zero-argument callable that runs one step on tensors at fixed addresses and synchronises with
     nothing -- into a HIP graph.  Warm-up runs on a side stream as torch.cuda.graph requires (allocator pools, lazy
     initialisation); the optimizer state those eager runs change is saved and restored, so capturing trains nothing.
-    Returns the graph."""
+
+    Warm-up and capture run on ONE stream (``stream``, or a new one), and ``before_capture()`` lets the caller drop whatever the
+    warm-up runs left behind (losses, outputs: their autograd graphs) before the capture starts: an autograd node that outlives the
+    warm-up -- an AccumulateGrad node above all -- is bound to the stream it was created on, and a captured backward that runs
+    through a node of ANOTHER stream synchronises with that stream inside the capture (_fresh_ray_leaves).  Returns the graph."""
     dev = opt.flat.data.device if opt is not None else estimator.occs.device
     estimator._occ_mean_device()                          # allocate / refresh the device-side alpha cap before the capture
     saved = (opt.flat.data.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count) if opt is not None else None
-    side = torch.cuda.Stream(device=dev)
+    side = stream if stream is not None else torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         for _ in range(warmup):
@@ -139,10 +178,12 @@ def capture_body(body, opt: Optional[FlatAdam], estimator, warmup: int = 3, pool
             body()
     torch.cuda.current_stream(dev).wait_stream(side)
     estimator.check_deferred_overflow()                   # (the eager warm-up runs' flags; one synchronisation, at construction)
+    if before_capture is not None:
+        before_capture()
     graph = torch.cuda.CUDAGraph()
     if opt is not None:
         opt.prepare_step()
-    with torch.cuda.graph(graph, pool=pool):
+    with torch.cuda.graph(graph, pool=pool, stream=side):
         body()
     # (the captured marcher calls OR into the estimator's sticky overflow accumulator at every replay, like the eager ones:
     #  LSEOccGridEstimator._overflow_flag -- read at the occupancy refresh and by check_overflow())
@@ -163,14 +204,16 @@ class GraphedTrainStep:
             # step.ray_grads: gradients w.r.t. the rays of this step (per bundle), for a pose optimiser outside the graph
 
     Earlier EAGER steps of the same model whose losses / outputs are still alive keep their autograd graphs and with them the
-    parameters' AccumulateGrad nodes, bound to the stream they were created on; a capture whose backward EXECUTES such a node leaves
-    the capturing stream (torch warns, the HIP runtime crashed in hipStreamEndCapture).  The step itself runs none: every parameter
-    of the fast path receives its gradient directly (the hash table, the MLPs, the embedding, and since round 4 the loss epilogue's
-    scalars: ops._scalar_param_grads; tests/test_gpu_graph.py runs the situation in a child process).  Parameters that only the
-    torch route updates (the MLP intensity mappers) still go through AccumulateGrad: with those, ``del`` old losses first.
+    parameters' AccumulateGrad nodes, bound to the stream they were created on; a capture whose backward hands a gradient to such a
+    node leaves the capturing stream (torch warns, the HIP runtime crashed in hipStreamEndCapture).  The step hands none over: every
+    parameter receives its gradient directly -- the hash table, the MLPs, the embedding, the loss epilogue's scalars
+    (ops._scalar_param_grads) and, since round 5, the parameters of the torch route as well (ops.direct_grad_params: MLP intensity
+    mappers, ``ThreeToOne``, ``Powpow`` outside the fused epilogue); the rays are fresh leaves in every run (_fresh_ray_leaves);
+    warm-up and capture share one stream and the warm-up's outputs are dropped before the capture (capture_body).
+    tests/test_gpu_graph.py runs captures behind live eager graphs in a child process, with that torch warning as an error.
 
-    ``ray_grads=True`` makes the static ray tensors leaves that require gradients (BASELINE config 4: BAD-NeRF pose
-    optimisation); their ``.grad`` after a replay is the gradient of the summed loss w.r.t. the rays that were copied in.
+    ``ray_grads=True``: the step differentiates w.r.t. the rays (BASELINE config 4: BAD-NeRF pose optimisation);
+    ``step.ray_grads`` after a replay holds the gradient of the summed loss w.r.t. the rays that were copied in.
     ``jitter``: "graph" draws the stratified offsets inside the graph; a tensor-valued call argument ``jitter=`` is copied
     into a static input instead when the object was built with ``jitter="input"``.
     ``prefetch_march=True`` (module docstring): announce the next step's rays with ``next_bundles=(col, prev, nxt)`` (and
@@ -190,7 +233,9 @@ class GraphedTrainStep:
         self.optimizer_in_graph = bool(optimizer_in_graph)
         self._deferred_before = (model.deferred_counts, model.deferred_max_slots)
         model.deferred_counts, model.deferred_max_slots = True, 1 << 62     # nothing inside the graph may wait for the host
-        self.col, self.prev, self.nxt = _static_bundles((col, prev, nxt), ray_grads)
+        self.col, self.prev, self.nxt = _static_bundles((col, prev, nxt))
+        self.want_ray_grads = bool(ray_grads)
+        self._ray_leaves: Optional[Tuple[Tensor, Tensor]] = None      # (origins, directions) leaves of the last run of _body
         self.batch = self._static_batch(batch)
         n_total = sum(len(b) for b in (self.col, self.prev, self.nxt) if b is not None)
         dev = opt.flat.data.device
@@ -202,20 +247,23 @@ class GraphedTrainStep:
         assert prefetch_fork in ("start", "hash_bwd")
         self.prefetch_fork = prefetch_fork
         self.replays = 0
+        self._capture_stream = torch.cuda.Stream(device=dev)           # warm-up runs AND captures (capture_body)
         if not self.prefetch:
-            self.graph = capture_body(self._body, opt, model.occupancy_grid, warmup)
+            self.graph = capture_body(self._body, opt, model.occupancy_grid, warmup, stream=self._capture_stream,
+                                      before_capture=self._drop_run)
             return
         # -- marcher of the next step on a side stream: two graphs alternate between two sample buffers
-        self.next_col, self.next_prev, self.next_nxt = _static_bundles((col, prev, nxt), False)
+        self.next_col, self.next_prev, self.next_nxt = _static_bundles((col, prev, nxt))
         self.next_jitter = torch.rand(n_total, device=dev) if jitter == "input" else None
         with torch.no_grad():
-            self._pm = [model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter) for _ in range(2)]
+            self._pm = [model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter, alias_blocks=True) for _ in range(2)]
         est = model.occupancy_grid
         self._side = torch.cuda.Stream(device=dev)
         self._graphs, self._losses_of, self._outputs_of, self._ray_grads_of = [], [], [], []
         for x in (0, 1):
             g = capture_body(lambda x=x: self._body_prefetch(x), opt, est, warmup if x == 0 else 1,
-                             pool=self._graphs[0].pool() if self._graphs else None)
+                             pool=self._graphs[0].pool() if self._graphs else None, stream=self._capture_stream,
+                             before_capture=self._drop_run)
             self._graphs.append(g)
             self._losses_of.append(self.losses)
             self._outputs_of.append(self.outputs)
@@ -236,14 +284,19 @@ class GraphedTrainStep:
                 out[k] = v.detach().clone() if torch.is_tensor(v) else v
         return out
 
+    def _drop_run(self):
+        """Forget the last run of ``_body`` (capture_body calls this between the warm-up runs and the capture): its losses and
+        outputs hold that run's autograd graph, and with it autograd nodes bound to the warm-up."""
+        self.losses, self.outputs, self._ray_leaves = {}, None, None
+
     def _body(self, premarched=None):
         self.opt.zero_grad()
-        for b in (self.col, self.prev, self.nxt):
-            if b is not None and _leaf(b.origins).requires_grad:
-                _leaf(b.origins).grad = None
-                _leaf(b.directions).grad = None
-        out, losses, _ = self.model.train_step_bundles(self.col, self.prev, self.nxt, self.batch, jitter=self.jitter,
-                                                       premarched=premarched)
+        col, prev, nxt = self.col, self.prev, self.nxt
+        if self.want_ray_grads:
+            (col, prev, nxt), o, d = _fresh_ray_leaves((col, prev, nxt))
+            self._ray_leaves = (o, d)
+        out, losses, _ = self.model.train_step_bundles(col, prev, nxt, self.batch, jitter=self.jitter,
+                                                       premarched=premarched, alias_blocks=True)
         # backward of rgb_loss + event_loss without forming the sum: every root gets the upstream gradient 1 from one static tensor
         # (the sum, its backward and the two ones_like fills were five ~5 us launches of every replay)
         vals = list(losses.values())
@@ -272,7 +325,8 @@ class GraphedTrainStep:
             cur = torch.cuda.current_stream()          # (the backward's stream when called from the autograd thread)
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side), torch.no_grad():
-                self.model.premarch_bundles(self.next_col, self.next_prev, self.next_nxt, jitter=self.next_jitter, out=self._pm[1 - x])
+                self.model.premarch_bundles(self.next_col, self.next_prev, self.next_nxt, jitter=self.next_jitter, out=self._pm[1 - x],
+                                            alias_blocks=True)
 
         table = self.model.field.mlp_base_grid.params
         saved = ops.get_hash_bwd_hook(table, "before")
@@ -289,19 +343,16 @@ class GraphedTrainStep:
         main.wait_stream(self._side)
 
     def _collect_ray_grads(self) -> Dict[str, Optional[Tuple[Tensor, Tensor]]]:
-        """Per bundle: the row block of the static ray buffers' gradient that belongs to it (one leaf per field for all bundles)."""
+        """Per bundle: the row block of the ray leaves' gradient that belongs to it (one leaf per field for all bundles)."""
         out, lo = {}, 0
+        go, gd = (self._ray_leaves[0].grad, self._ray_leaves[1].grad) if self._ray_leaves is not None else (None, None)
+        single = sum(b is not None for b in (self.col, self.prev, self.nxt)) == 1
         for k, b in (("col", self.col), ("prev", self.prev), ("next", self.nxt)):
             if b is None:
                 out[k] = None
                 continue
             hi = lo + len(b)
-            if not _leaf(b.origins).requires_grad:
-                out[k] = None
-            else:
-                go, gd = _leaf(b.origins).grad, _leaf(b.directions).grad
-                whole = b.origins._base is None
-                out[k] = (go if whole else go[lo:hi], gd if whole else gd[lo:hi]) if go is not None else None
+            out[k] = None if go is None else ((go, gd) if single else (go[lo:hi], gd[lo:hi]))
             lo = hi
         return out
 
@@ -369,7 +420,7 @@ class GraphedTrainStep:
         if self._pm_version is None or self._pm_version != est.grid_version:
             # nothing was marched ahead for these rays, or the grid has been refreshed since: march them now (eagerly, same stream)
             with torch.no_grad():
-                self.model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter, out=self._pm[x])
+                self.model.premarch_bundles(self.col, self.prev, self.nxt, jitter=self.jitter, out=self._pm[x], alias_blocks=True)
         if next_bundles is not None:         # (the announced rays themselves were copied in by __call__, with this step's inputs)
             if self.next_jitter is not None:
                 if next_jitter is None:

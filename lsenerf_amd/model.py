@@ -549,6 +549,16 @@ class LSENeRFModel(nn.Module):
     def get_outputs(self, ray_bundle: RayBundle, ev_out=False, jitter: Optional[Tensor] = None, **kwargs):
         return self.route_outputs(self.exec_get_outputs(ray_bundle, jitter=jitter), ray_bundle, ev_out=ev_out, **kwargs)
 
+    @staticmethod
+    def _run_module(module, *args, **kwargs):
+        """``module(*args)`` with its parameters' gradients accumulated straight into their preallocated buffers
+        (ops.direct_grad_params): on the torch route of the loss too, no AccumulateGrad node of a model parameter receives a
+        gradient -- which is what keeps a captured step indifferent to autograd graphs of earlier eager steps (graph.py)."""
+        direct = ops.direct_grad_params(module) if isinstance(module, nn.Module) else None
+        if direct is None:
+            return module(*args, **kwargs)
+        return torch.func.functional_call(module, direct, args, kwargs)
+
     def route_outputs(self, out_dict: Dict[str, Tensor], ray_bundle: RayBundle, ev_out=False, **kwargs):
         """Rendered radiance -> the reference's output keys: "rgb" in display space, "linear" / "ev_linear" / "ev_out" on
         the event side, by map_mode ("rgb_evs": render -> rgb -> events; "evs_rgb": render -> events -> rgb; "co_map":
@@ -558,18 +568,21 @@ class LSENeRFModel(nn.Module):
         linear = radiance.clamp_min(1e-5)
         events_wanted = ev_out or not training
         routed = dict(out_dict)
+        rgb_mapper = lambda *a, **k: self._run_module(self.rgb_mapper, *a, **k)
+        evs_mapper = lambda *a, **k: self._run_module(self.evs_mapper, *a, **k)
+        correct_evs_dim = lambda *a, **k: self._run_module(self.correct_evs_dim, *a, **k)
         if plan["mode"] == "rgb_evs":
             if events_wanted:
-                routed["ev_out"] = self.rgb_mapper(self.correct_evs_dim(linear))
+                routed["ev_out"] = rgb_mapper(correct_evs_dim(linear))
                 routed["linear"] = format_linear(routed["ev_out"])
         elif plan["mode"] == "evs_rgb":
-            routed.update(ev_out=self.correct_evs_dim(linear), linear=linear, rgb=self.rgb_mapper(linear).to(linear))
+            routed.update(ev_out=correct_evs_dim(linear), linear=linear, rgb=rgb_mapper(linear).to(linear))
         elif plan["mode"] == "co_map":
-            routed["rgb"] = self.rgb_mapper(linear)
+            routed["rgb"] = rgb_mapper(linear)
             if events_wanted:
-                ev_linear = self.correct_evs_dim(linear)
+                ev_linear = correct_evs_dim(linear)
                 routed.update(linear=linear, ev_linear=ev_linear,
-                              ev_out=self.evs_mapper(ev_linear, raybd1=ray_bundle, **kwargs))
+                              ev_out=evs_mapper(ev_linear, raybd1=ray_bundle, **kwargs))
         rgb = routed["rgb"]
         if training and plan["deblur_group"] > 1 and rgb.shape[-1] == 3 and rgb.shape[0] % plan["deblur_group"] == 0:
             rgb = rgb.reshape(-1, plan["deblur_group"], 3).mean(dim=1)          # the virtual cameras of one pixel
@@ -616,7 +629,7 @@ class LSENeRFModel(nn.Module):
     # -- the reference's training step (R:lse_nerf/lse_pipeline.py:110-145) as ONE packed pass ----------------------------
     def train_step_bundles(self, col_bundle: Optional[RayBundle], prev_bundle: Optional[RayBundle],
                            next_bundle: Optional[RayBundle], batch: Dict[str, object], jitter: Optional[Tensor] = None,
-                           with_metrics: bool = False, premarched=None):
+                           with_metrics: bool = False, premarched=None, alias_blocks: bool = False):
         """``LSENeRFPipeline.get_train_loss_dict`` for bundles the data manager has already produced: returns
         ``(out_dict, loss_dict, metrics_dict)`` with ``out_dict = {"col_out", "prev_out", "next_out"}``.
 
@@ -629,14 +642,16 @@ class LSENeRFModel(nn.Module):
         offset per ray, colour rays first, for callers that need the draw reproduced); only the order in which gradient
         contributions are summed differs.  ``premarched``: the result of ``premarch_bundles`` for these bundles (the ray marcher
         run ahead of the step; ``jitter`` was applied there).  ``with_metrics``: also route the colour render and report NGPModel's psnr /
-        num_samples_per_batch (R:lse_nerf/lsenerf.py:378-388) -- a handful of O(R) torch ops outside the fused epilogue."""
+        num_samples_per_batch (R:lse_nerf/lsenerf.py:378-388) -- a handful of O(R) torch ops outside the fused epilogue.
+        ``alias_blocks``: the bundles are the caller's own row blocks of one buffer per field and may be joined without a copy
+        (``RayBundle.cat``; lsenerf_amd.graph's static inputs)."""
         assert self.training, "train_step_bundles is the training step; use forward() / get_outputs() for evaluation"
         names = ("col_out", "prev_out", "next_out")
         given = [(k, b) for k, b in zip(names, (col_bundle, prev_bundle, next_bundle)) if b is not None and len(b) > 0]
         assert given, "no rays in this step"
         if (prev_bundle is not None and len(prev_bundle) > 0) != (next_bundle is not None and len(next_bundle) > 0):
             raise ValueError("previous and next event bundles come in pairs")
-        rb = RayBundle.cat([b for _, b in given])
+        rb = RayBundle.cat([b for _, b in given], alias_blocks=alias_blocks)
         if self.collider is not None:
             rb = self.collider(rb)
         raw = self.exec_get_outputs(rb, jitter=jitter, premarched=premarched)
@@ -657,13 +672,14 @@ class LSENeRFModel(nn.Module):
         return out_dict, loss_dict, metrics_dict
 
     def premarch_bundles(self, col_bundle: Optional[RayBundle], prev_bundle: Optional[RayBundle],
-                         next_bundle: Optional[RayBundle], jitter: Optional[Tensor] = None, out=None):
+                         next_bundle: Optional[RayBundle], jitter: Optional[Tensor] = None, out=None,
+                         alias_blocks: bool = False):
         """The ray marcher of ``train_step_bundles`` for these bundles, launched now (on torch's current stream): it reads the rays
         and the occupancy grid only, so the NEXT step's marcher can run behind the current step's backward pass.  The result is
         valid while ``occupancy_grid.grid_version`` equals its ``grid_version``."""
         cfg = self.config
         given = [b for b in (col_bundle, prev_bundle, next_bundle) if b is not None and len(b) > 0]
-        rb = RayBundle.cat(given)
+        rb = RayBundle.cat(given, alias_blocks=alias_blocks)
         if self.collider is not None:
             rb = self.collider(rb)
         return self.sampler.premarch(rb, near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size,

@@ -434,6 +434,35 @@ def _direct_grad(p: torch.Tensor):
     return None
 
 
+class _DirectGradFn(torch.autograd.Function):
+    """Identity on a leaf parameter whose gradient buffer exists (``_direct_grad``): the backward adds the incoming gradient into
+    that buffer and hands NOTHING on, so the parameter's AccumulateGrad node never receives a gradient.  For parameters that plain
+    torch ops consume (the torch route of the loss: MLP intensity mappers, ``ThreeToOne``, ``Powpow``) -- the kernels of the fast
+    path write their parameter gradients in place already."""
+
+    @staticmethod
+    def forward(ctx, p):
+        ctx.param = p
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        direct = _direct_grad(ctx.param)
+        if direct is None:
+            return g
+        direct.add_(g)
+        return None
+
+
+def direct_grad_params(module: torch.nn.Module) -> Optional[dict]:
+    """``{name: tensor}`` for ``torch.func.functional_call(module, ...)``: every parameter of ``module`` that has a preallocated
+    gradient buffer behind ``_DirectGradFn``.  None when there is nothing to redirect (no such parameter, or no autograd)."""
+    if not torch.is_grad_enabled():
+        return None
+    out = {n: _DirectGradFn.apply(p) for n, p in module.named_parameters() if _direct_grad(p) is not None}
+    return out or None
+
+
 _HASH_BWD_WS = {}      # (device index, stream) -> zeroed workspace of the hash backward's coarse-level replicas
 
 

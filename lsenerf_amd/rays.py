@@ -46,15 +46,18 @@ class RayBundle:
         return self.origins.shape[0]
 
     @staticmethod
-    def cat(bundles) -> "RayBundle":
+    def cat(bundles, alias_blocks: bool = False) -> "RayBundle":
         """One bundle holding the rays of ``bundles`` in order (autograd flows back to every part).  An optional field must be
-        present in all parts or in none; metadata keys likewise."""
+        present in all parts or in none; metadata keys likewise.  The result owns fresh tensors (``torch.cat``) -- in-place work on
+        it never reaches the parts.  ``alias_blocks=True`` is the opt-in of callers whose parts are THEIR OWN consecutive row blocks
+        of one buffer per field (lsenerf_amd.graph's static inputs): the join is then that buffer itself, no copy, no autograd node
+        -- and an alias of the parts, so such callers must not write to the joined bundle in place."""
         bundles = list(bundles)
         if len(bundles) == 1:
             return bundles[0]
 
         def join_vals(vals):
-            base = _whole_base(vals)       # the parts ARE one tensor cut into consecutive row blocks: no copy, no autograd node
+            base = _whole_base(vals) if alias_blocks else None
             return base if base is not None else torch.cat(vals, dim=0)
 
         def join(name):

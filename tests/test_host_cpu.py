@@ -362,20 +362,27 @@ def test_hash_bwd_replica_workspace_is_bounded_by_a_byte_budget():
 
 def test_raybundle_cat_of_row_blocks_of_one_buffer_is_that_buffer():
     """lsenerf_amd.graph keeps the three bundles of a captured step as row blocks of one static buffer per field, so that joining them
-    (RayBundle.cat, inside LSENeRFModel.train_step_bundles) costs no kernel and the ray gradients arrive in ONE leaf."""
+    (RayBundle.cat(alias_blocks=True), inside LSENeRFModel.train_step_bundles) costs no kernel and the ray gradients arrive in ONE leaf.
+    The alias is the OPT-IN of callers that own the blocks: the plain join keeps torch.cat's semantics (a fresh tensor; in-place work
+    on the joined bundle never reaches a data manager's source rays)."""
     from lsenerf_amd import RayBundle
     base_o = torch.randn(10, 3, requires_grad=True)
     base_d = torch.randn(10, 3)
     ids = torch.arange(10)
     parts = [RayBundle(origins=base_o[a:b], directions=base_d[a:b], metadata={"appearance_id": ids[a:b]}) for a, b in ((0, 4), (4, 7), (7, 10))]
-    rb = RayBundle.cat(parts)
+    plain = RayBundle.cat(parts)
+    assert plain.origins is not base_o and plain.origins.data_ptr() != base_o.data_ptr() and torch.equal(plain.origins, base_o)
+    v0 = base_d._version
+    plain.directions.mul_(2.0)                                 # (what a collider / normalisation may do to the joined bundle)
+    assert base_d._version == v0 and not torch.equal(plain.directions, base_d)
+    rb = RayBundle.cat(parts, alias_blocks=True)
     assert rb.origins is base_o and rb.directions is base_d and rb.metadata["appearance_id"] is ids
     (rb.origins * 2).sum().backward()
     assert torch.equal(base_o.grad, torch.full((10, 3), 2.0))
     # anything else is a real concatenation: a gap, another order, parts of different tensors, a partial cover
     for sel in (((0, 4), (5, 10)), ((4, 7), (0, 4), (7, 10)), ((0, 4), (4, 7))):
         p2 = [RayBundle(origins=base_o[a:b], directions=base_d[a:b]) for a, b in sel]
-        r2 = RayBundle.cat(p2)
+        r2 = RayBundle.cat(p2, alias_blocks=True)
         assert r2.origins is not base_o and torch.equal(r2.origins, torch.cat([base_o[a:b] for a, b in sel]))
     mixed = RayBundle.cat([RayBundle(origins=base_o[0:4], directions=base_d[0:4]), RayBundle(origins=torch.zeros(2, 3), directions=torch.zeros(2, 3))])
     assert mixed.origins.shape == (6, 3)
