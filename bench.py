@@ -70,9 +70,17 @@ MLP_BF16_FLOP_PER_SAMPLE = (180 + 96 + 528 + 244) * 16384 // 32
 HBM_PEAK = 8.0e12                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_workload(device, seed, kind="sphere"):
+N_RAY_SETS = 8                         # the timed loop cycles this many pre-generated (rays, targets, stratified offsets) sets
+
+
+def build_workload(device, seed, kind="sphere", n_sets=1):
     """kind "sphere": SURVEY 8d M-march exactly (the headline).  kind "inside": the round-1/2 headline (origins in
-    [-0.5, 0.5]^3, 4-level grid, per-ray t_max capped: exactly 1024 samples per ray, 65 % of them in the contracted shell)."""
+    [-0.5, 0.5]^3, 4-level grid, per-ray t_max capped: exactly 1024 samples per ray, 65 % of them in the contracted shell).
+
+    Returns ``(model, sets, counts)``: ``sets`` = ``n_sets`` tuples ``(ray bundle, target, jitter)``, all resident in HBM -- a training
+    step draws NEW pixels and a new stratified offset per ray every step (R:lse_nerf/lse_datamanager.py:135-144,
+    R:lse_nerf/lse_grid_estimator.py:85-87), so the timed loop cycles the sets instead of replaying one input; ``counts`` = the
+    samples each set yields at the calibrated step size."""
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
     torch.manual_seed(96)                                     # identical parameters on every rank
     inside = kind == "inside"
@@ -82,30 +90,39 @@ def build_workload(device, seed, kind="sphere"):
     model.occupancy_grid.mark_all_occupied()
     g = torch.Generator().manual_seed(seed)                   # rank-dependent rays (R:train.py:104 seeds by rank)
     R = RAYS_PER_GPU
-    if inside:
-        o = (torch.rand(R, 3, generator=g) - 0.5)
-        d = torch.randn(R, 3, generator=g)
-        d = d / d.norm(dim=-1, keepdim=True)
-        step = cfg.render_step_size
-        fars = torch.full((R, 1), cfg.near_plane + SAMPLES_PER_RAY * step - 0.25 * step).to(device)
-    else:
-        o, d = sphere_rays(R, g)
-        fars = None
-    target = torch.rand(R, 3, generator=g)
-    jitter = torch.zeros(R)                                   # fixed draw: the sample count does not change from step to step
-    rb = RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
-                   camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device), fars=fars,
-                   metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(device)})
+    sets = []
+    for k in range(n_sets):
+        if inside:
+            o = (torch.rand(R, 3, generator=g) - 0.5)
+            d = torch.randn(R, 3, generator=g)
+            d = d / d.norm(dim=-1, keepdim=True)
+            step = cfg.render_step_size
+            fars = torch.full((R, 1), cfg.near_plane + SAMPLES_PER_RAY * step - 0.25 * step).to(device)
+        else:
+            o, d = sphere_rays(R, g)
+            fars = None
+        target = torch.rand(R, 3, generator=g)
+        # stratified sampling: one offset in [0, 1) steps per ray and step.  A single set keeps the round-1..4 fixed draw (zeros),
+        # so that the one-set context workloads stay comparable with the earlier rounds
+        jitter = torch.rand(R, generator=g) if n_sets > 1 else torch.zeros(R)
+        rb = RayBundle(origins=o.to(device).requires_grad_(True), directions=d.to(device).requires_grad_(True),
+                       camera_indices=torch.zeros(R, 1, dtype=torch.long, device=device), fars=fars,
+                       metadata={"appearance_id": torch.randint(0, 64, (R,), generator=g).to(device)})
+        sets.append((rb, target.to(device), jitter.to(device)))
+    est = model.occupancy_grid
+
+    def counts():
+        return [est.sampling(rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                             t_max=rb.fars.reshape(-1) if rb.fars is not None else None, render_step_size=cfg.render_step_size,
+                             stratified=True, jitter=jit, return_packed=True)[1].shape[0] for rb, _, jit in sets]
     if not inside:
         # "step chosen so the mean count is ~1024 per ray": the count is ~ (chord inside the box) / step, so one marcher
-        # call at the reference's step and one correction settle it (the same rule on every rank; rays differ by rank)
-        est = model.occupancy_grid
+        # call per set at the reference's step and two corrections settle the MEAN over the sets (the same rule on every rank;
+        # rays differ by rank).  A single set's count then sits within ~1 % of 1024 per ray (4096 independent chords)
         for _ in range(3):
-            n = est.sampling(rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,
-                             render_step_size=cfg.render_step_size, stratified=True, jitter=jitter.to(device),
-                             return_packed=True)[1].shape[0]
+            n = sum(counts()) / n_sets
             cfg.render_step_size = float(cfg.render_step_size * n / (R * SAMPLES_PER_RAY))
-    return model, rb, target.to(device), jitter.to(device)
+    return model, sets, counts()
 
 
 def train_step(model, rb, target, jitter, opt, world, exchange=None, pipeline=None, sharded=None, graphed=None, exposed=None):
@@ -231,16 +248,18 @@ def _drop_autograd_graphs(holder):
     gc.collect()
 
 
-def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None, prefetch=False):
+def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_from=None, prefetch=False, cycle=None):
     """The same step as ONE replayed HIP graph (lsenerf_amd.graph.GraphedTrainStep: device-side sample counts, staged Adam
     scalars, jitter drawn inside the graph; the occupancy refresh stays an eager in-place call between replays).
     ``prefetch``: the graph also marches the NEXT step's rays on a side stream (here: the same rays, announced at every call; on the
     refresh steps the samples marched ahead are stale and the rays are marched again, inside the timing).
+    ``cycle``: a list of (col, prev, nxt, batch) inputs of the captured composition, resident in HBM, that the replays cycle through
+    (the graph copies the step's inputs into its static buffers: new rays every step, as in training).
     Returns {"ms_per_step", "host_ms_per_step"}."""
     from lsenerf_amd.graph import GraphedTrainStep
     step = GraphedTrainStep(model, opt, col, prev, nxt, batch, ray_grads=True, prefetch_march=prefetch,
                             prefetch_fork=os.environ.get("LSE_BENCH_PREFETCH_FORK", "hash_bwd"))
-    kw = {"next_bundles": (col, prev, nxt)} if prefetch else {}
+    cycle = cycle or [(col, prev, nxt, batch)]
     k = 0
 
     def run(n):
@@ -248,7 +267,9 @@ def _graphed_timing(model, opt, col, prev, nxt, batch, steps, warmup, refresh_fr
         for _ in range(n):
             if refresh_from is not None:
                 model.update_occupancy_grid(refresh_from + k)
-            step(col, prev, nxt, batch, **kw)
+            c, p_, x, b = cycle[k % len(cycle)]
+            kw = {"next_bundles": cycle[(k + 1) % len(cycle)][:3]} if prefetch else {}
+            step(c, p_, x, b, **kw)
             k += 1
     run(warmup)
     torch.cuda.synchronize()
@@ -365,7 +386,8 @@ def context_default_config(device, steps=20, warmup=6):
 def context_inside_box(device, steps=12, warmup=4):
     """The round-1/2 headline workload as context: origins inside the box, 4-level grid, exactly 1024 samples per ray."""
     from lsenerf_amd.optim import FlatAdam, FlatParams
-    model, rb, target, jitter = build_workload(device, seed=1000, kind="inside")
+    model, sets, _ = build_workload(device, seed=1000, kind="inside")
+    rb, target, jitter = sets[0]
     flat = FlatParams(model.get_param_groups()["fields"])
     opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
     last = {}
@@ -587,8 +609,8 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)         # "Warm-up 20 steps, time 100 steps"
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the default-config / M-packed context runs")
     ap.add_argument("--no-atomic-floor", action="store_true",
@@ -621,7 +643,8 @@ def main():
     torch.cuda.set_device(device)
     _lib.load()
 
-    model, rb, target, jitter = build_workload(device, seed=1000 + rank)
+    model, sets, set_counts = build_workload(device, seed=1000 + rank, n_sets=N_RAY_SETS)
+    rb, target, jitter = sets[0]
     flat = FlatParams(model.get_param_groups()["fields"], total_multiple=world * 64)
     ldist.broadcast_params(flat.data)
     opt = FlatAdam(flat, lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
@@ -655,8 +678,14 @@ def main():
     if pipeline is not None:
         pipeline.exposed_events = exposed
 
+    step_no = 0
+
     def one_step():
-        return train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded, graphed, exposed)
+        # every step trains on the next of the N_RAY_SETS resident (rays, targets, stratified offsets) sets
+        nonlocal step_no
+        rb_k, target_k, jitter_k = sets[step_no % len(sets)]
+        step_no += 1
+        return train_step(model, rb_k, target_k, jitter_k, opt, world, exchange, pipeline, sharded, graphed, exposed)
 
     n_samples = 0
     for _ in range(args.warmup):
@@ -686,7 +715,11 @@ def main():
     timing = _lib.TIMING
     _lib.TIMING = None
     elapsed = ldist.max_over_ranks(elapsed, device)
-    n_samples = int(n_samples)                 # the device-side count of the last step, read once, after the timed region
+    n_last = int(n_samples)                    # the device-side count of the last step, read once, after the timed region
+    assert n_last == set_counts[(step_no - 1) % len(sets)], (n_last, set_counts)      # the timed steps marched what the set-up counted
+    # samples per step = the mean over the sets the K timed steps actually cycled through (the counts differ by < 1 % between sets)
+    timed_sets = [(args.warmup + i) % len(sets) for i in range(args.steps)]
+    n_samples = int(round(sum(set_counts[k] for k in timed_sets) / max(len(timed_sets), 1)))
     model.occupancy_grid.check_deferred_overflow()
     # what the gradient exchange still costs per step after whatever overlap the mode has: stream time between the two events that
     # bracket the wait for (or, in the blocking modes, the whole of) the collective; max over ranks like the step time
@@ -708,7 +741,7 @@ def main():
         graphed.close()
         graphed = None
         model.deferred_counts = True
-    kern_ms, launches = _event_pass(lambda i: train_step(model, rb, target, jitter, opt, world, exchange, pipeline, sharded),
+    kern_ms, launches = _event_pass(lambda i: train_step(model, *sets[i % len(sets)], opt, world, exchange, pipeline, sharded),
                                     0, bsteps, None)
     if pipeline is not None:
         pipeline.flush()
@@ -717,6 +750,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         rays_per_s = world * RAYS_PER_GPU / (elapsed / args.steps)
         assert abs(n_samples / (RAYS_PER_GPU * SAMPLES_PER_RAY) - 1.0) < 0.01, f"workload drifted: {n_samples} samples"
+        assert all(abs(c / (RAYS_PER_GPU * SAMPLES_PER_RAY) - 1.0) < 0.03 for c in set_counts), set_counts
         dom_src = "HIP events around the entry point inside the timed region"
         if not dom_ms_all:      # exchange mode "graphed": a replayed graph has no host hooks between its kernels
             dom_ms_all = {k: kern_ms[k] for k in ("lse_hash_bwd", "lse_hash_fwd") if k in kern_ms}
@@ -752,6 +786,7 @@ def main():
                 x01_ = ops.positions(rb.origins.detach(), rb.directions.detach(), ri_, ts_, te_, pk_, True, None)[0]
                 req = hash_bwd_request_floor(x01_, model.field.mlp_base_grid.meta)
                 del ri_, ts_, te_, pk_, x01_
+            req = req / set_counts[0] * n_samples        # (counted on the first ray set; the launches average over all sets)
             atomic = {"bound": "memory-side float atomics (requests of <= 64 B)", "request_floor_per_launch": req,
                       "requests_per_sample": req / n_samples, "peak_requests_per_s": 21e9,
                       "achieved_requests_per_s": req / (dom_ms * 1e-3), "frac": req / (dom_ms * 1e-3) / 21e9,
@@ -762,10 +797,15 @@ def main():
             "n_gpus": world, "ranks_seen": ranks_seen, "backend": (tdist.get_backend() if tdist.is_initialized() else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "M-march (SURVEY 8d, exact): LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, "
-                                   "SH4, 32-d appearance embedding); 4096 rays/GPU from the radius-1.5 sphere aimed into "
-                                   "[-0.5,0.5]^3, one-level 128^3 occupancy grid fully occupied, cone 0, no culling, constant step "
-                                   "chosen for 1024 samples per ray on average; sampler + fwd + bwd + Adam, grads w.r.t. rays included",
+            "config": {"workload": "M-march (SURVEY 8d): 4096 rays x ~1024 samples per GPU, L=16 T=2^19 hash grid + 64-wide fused MLPs",
+                       "step_roofline_frac": b_step / (ms_per_step * 1e-3) / HBM_PEAK, "roofline_frac": achieved / (HBM_PEAK / 1e9),
+                       "workload_detail": "SURVEY 8d exactly: LSENeRF scene field (L=16 hash grid T=2^19 F=2, 64-wide fused MLPs, "
+                                          "SH4, 32-d appearance embedding); 4096 rays/GPU from the radius-1.5 sphere aimed into "
+                                          "[-0.5,0.5]^3, one-level 128^3 occupancy grid fully occupied, cone 0, no culling, constant step "
+                                          "chosen for 1024 samples per ray on average; sampler + fwd + bwd + Adam, grads w.r.t. rays "
+                                          "included; every step trains on the next of %d resident (rays, targets, stratified offsets) "
+                                          "sets" % len(sets),
+                       "ray_sets": len(sets), "samples_per_set": set_counts,
                        "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": n_samples / RAYS_PER_GPU, "samples_per_step": n_samples,
                        "render_step_size": model.config.render_step_size,
                        "parallelism": f"dp{world}", "grad_exchange": mode,
@@ -804,14 +844,15 @@ def main():
         if world == 1 and not args.no_context:
             # the headline workload as one replayed graph (pre-pass off as SURVEY 8d prescribes: no density_fn on the sampler)
             model.sampler.density_fn = None
+            cyc = [(rb_k, None, None, {"col_batch": {"image": t_k}, "evs_batch": None}) for rb_k, t_k, _ in sets]
             line["m_march_graphed"] = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
-                                                      min(args.steps, 20), 4)
+                                                      min(args.steps, 20), 4, cycle=cyc)
             line["m_march_graphed"]["rays_per_s"] = RAYS_PER_GPU / (line["m_march_graphed"]["ms_per_step"] * 1e-3)
             pf = _graphed_timing(model, opt, rb, None, None, {"col_batch": {"image": target}, "evs_batch": None},
-                                 min(args.steps, 20), 4, prefetch=True)
+                                 min(args.steps, 20), 4, prefetch=True, cycle=cyc)
             pf["rays_per_s"] = RAYS_PER_GPU / (pf["ms_per_step"] * 1e-3)
             line["m_march_graphed"]["marcher_prefetched"] = pf
-            del model, flat, opt
+            del model, flat, opt, cyc
             torch.cuda.empty_cache()
             line["m_march_inside_box"] = context_inside_box(device)
             torch.cuda.empty_cache()

@@ -468,3 +468,110 @@ def test_single_rank_collectives_switch_runs_every_collective_and_changes_nothin
         ((model(x) - y) ** 2).mean().backward()
         ex.step()
     assert torch.equal(res["p"], flat.data)
+
+
+# ---- config 5's exact split on CPU: 8 ranks x 4096 of 32768 rays (R:lse_nerf/lse_pipeline.py:95-98) ------------------
+class _TinyField(torch.nn.Module):
+    """A field-shaped toy: a 'table' gathered by position (odd size), two small MLP matrices and a 200-float tail -- 1565 parameters
+    in a 2048-float buffer (each parameter 64-aligned, the total a multiple of 8 x 64), which the 8 shards of 256 floats cut in the
+    MIDDLE of the table, of a weight matrix and of the tail; the last rank's shard is padding only."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.table = torch.nn.Parameter(torch.randn(1101, generator=g) * 0.1)
+        self.w0 = torch.nn.Parameter(torch.randn(24, 8, generator=g) * 0.3)
+        self.w1 = torch.nn.Parameter(torch.randn(3, 24, generator=g) * 0.3)
+        self.tail = torch.nn.Parameter(torch.randn(200, generator=g) * 0.1)
+
+    def forward(self, o, d):
+        idx = ((o.abs().sum(-1) * 997.0).long() % 1101)
+        feat = torch.cat([o, d, self.table[idx][:, None], self.tail[idx % 200][:, None]], dim=-1)       # [R, 8]
+        return torch.sigmoid(torch.relu(feat @ self.w0.t()) @ self.w1.t())
+
+
+def _world8_rays():
+    g = torch.Generator().manual_seed(96)
+    o, d = torch.randn(32768, 3, generator=g), torch.randn(32768, 3, generator=g)
+    return o, d / d.norm(dim=-1, keepdim=True), torch.rand(32768, 3, generator=g)
+
+
+def _world8_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from lsenerf_amd import dist as ldist
+    from lsenerf_amd.optim import FlatParams
+    r, w, _ = ldist.init_from_env("gloo")
+    assert (r, w) == (rank, 8)
+    o, d, y = _world8_rays()
+    sl = ldist.shard_rays(32768, rank, world)
+    assert sl == slice(4096 * rank, 4096 * (rank + 1))
+    finals = {}
+    for mode in ("plain", "pipelined_sharded", "sharded"):
+        model = _TinyField()
+        if rank:        # de-synchronise on purpose: broadcast_params must repair it
+            with torch.no_grad():
+                model.tail.add_(float(rank))
+        flat = FlatParams(model.parameters(), total_multiple=world * 64)
+        assert flat.data.numel() == 2048 and sum(p.numel() for p in model.parameters()) == 1565
+        ldist.broadcast_params(flat.data)
+        opt = _ToyOpt(flat)
+        est = _ToyEstimator()
+        sharded = ldist.ShardedAdamExchange(flat, lr=opt.lr, adam_fn=_adam_fn_cpu) if mode != "plain" else None
+        if sharded is not None:
+            # in place on the flat buffers (no staging copies), and every shard border lies strictly INSIDE a parameter: table | w0 |
+            # w1 | tail start at 0, 1152, 1344, 1472 and end at 1672; the borders are the multiples of 256, the last of them (1792)
+            # lies in the padding: rank 7 reduces, updates and gathers a shard that holds no parameter at all
+            assert sharded.per == 256 and sharded.padded == 2048 and sharded.param_full is None and sharded.grad_full is None
+            assert flat.offsets == [0, 1152, 1344, 1472]
+            for b in range(256, 1672, 256):
+                assert any(o_ < b < o_ + p_.numel() for o_, p_ in zip(flat.offsets, flat.params)), b
+        pipe = ldist.GradPipeline(opt, world, sharded=sharded).attach(est) if mode == "pipelined_sharded" else None
+        for step in range(3):
+            est.sampling(lambda: None)                  # (the marcher of this step: the pipeline finishes the previous step here)
+            opt.zero_grad()
+            ((model(o[sl], d[sl]) - y[sl]) ** 2).mean().backward()
+            if pipe is not None:
+                pipe.start()
+            elif sharded is not None:
+                sharded.lr = opt.current_lr()
+                opt.step_count += 1
+                sharded.step()
+            else:
+                ldist.allreduce_grads(flat.grad)
+                opt.step(grad_scale=1.0 / world)
+        if pipe is not None:
+            pipe.flush()
+        assert opt.step_count == 3
+        finals[mode] = flat.data.clone()
+    torch.save(finals, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_8_split_of_config_5_on_cpu(tmp_path):
+    """BASELINE config 5 as named -- 32768 rays over 8 ranks, one exchange of the flat gradient per step -- over gloo on the CPU (no
+    8-GPU node has been available in any round): ``shard_rays(32768, r, 8)``, ``FlatParams(total_multiple=8 * 64)``,
+    ``ShardedAdamExchange`` (blocking and behind ``GradPipeline``) and the plain all-reduce, on a field-shaped toy whose shard borders
+    fall inside parameters and whose flat buffer has a padded tail.  Every rank ends with the same bits; all three exchanges equal
+    ONE process on the full batch."""
+    out = str(tmp_path / "p")
+    mp.spawn(_world8_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    got = [torch.load(out + f".{r}") for r in range(8)]
+    for mode in ("plain", "pipelined_sharded", "sharded"):
+        for r in range(1, 8):
+            assert torch.equal(got[r][mode], got[0][mode]), (mode, r)        # replicas stay replicas
+    from lsenerf_amd.optim import FlatParams
+    model = _TinyField()
+    flat = FlatParams(model.parameters(), total_multiple=8 * 64)
+    o, d, y = _world8_rays()
+    state = {"m": torch.zeros_like(flat.data), "v": torch.zeros_like(flat.data)}
+    for step in range(1, 4):
+        flat.zero_grad()
+        ((model(o, d) - y) ** 2).mean().backward()
+        _adam_cpu(flat, state, 1e-2, 1.0, step)
+    for mode in ("plain", "pipelined_sharded", "sharded"):
+        assert torch.allclose(got[0][mode], flat.data, rtol=0, atol=2e-6), (mode, float((got[0][mode] - flat.data).abs().max()))
+    assert torch.equal(got[0]["pipelined_sharded"], got[0]["sharded"])      # the pipeline reorders launches, not arithmetic
+    assert bool((got[0]["plain"][1672:] == 0).all())                         # the padded tail never moves
