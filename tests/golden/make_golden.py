@@ -73,6 +73,48 @@ def make_hash():
          scalings=meta.scalings.numpy())
 
 
+BIG_HASH = ((4, 10), (16, 12), (16, 19))        # (levels, log2 table size): SURVEY 8c (i) at 4096 points; T = 19 is the production size
+BIG_N, BIG_STRIDE = 4096, 8
+
+
+def level_sums(t, meta, L, absolute=False):
+    """float64 sum (of absolute values) of every level's slice of a flat table-shaped tensor."""
+    f = (lambda v: v.abs()) if absolute else (lambda v: v)
+    return np.array([float(f(t[2 * meta.offsets[l]:2 * meta.offsets[l + 1]].double()).sum()) for l in range(L)])
+
+
+def make_hash_big():
+    """4096-point fixtures of the tcnn layout, stored COMPACTLY: the table (48.8 MB at T = 19) and the upstream gradient ``w`` are
+    regenerated from the stored seed by ``hash_inputs`` (torch's CPU generator is platform independent); of the outputs every 8th
+    row of ``y`` is stored in full, plus per-level float64 sums / absolute sums of ALL rows and of the whole table gradient, ``dx`` in
+    full, and the corner indices of the first hashed and the last level (the bit-exact integer side)."""
+    for L, T in BIG_HASH:
+        meta, table, x, w = hash_inputs(L, T, BIG_N, SEED + 100 * T + L)
+        tc, xc = table.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y = hg.hash_encode_tcnn(xc, tc, meta)
+        (y * w).sum().backward()
+        yd = y.detach().double().reshape(BIG_N, L, 2)
+        hashed = [l for l in range(L) if not meta.is_dense(l)]
+        save(f"hash_tcnn_L{L}_T{T}_n{BIG_N}", L=L, T=T, n=BIG_N, seed=SEED + 100 * T + L, stride=BIG_STRIDE, x=x.numpy(),
+             y_rows=y.detach()[::BIG_STRIDE].numpy(), y_level_sums=yd.sum(dim=(0, 2)).numpy(), y_level_abs_sums=yd.abs().sum(dim=(0, 2)).numpy(),
+             dx=xc.grad.numpy(), dtable_level_sums=level_sums(tc.grad, meta, L), dtable_level_abs_sums=level_sums(tc.grad, meta, L, True),
+             dtable_head=tc.grad[:4096].numpy(), table_checksum=bits_checksum(table.numpy()), w_checksum=bits_checksum(w.numpy()),
+             first_hashed_level=(hashed[0] if hashed else -1),
+             idx_first_hashed=(hg.tcnn_corner_indices(x, meta, hashed[0]).numpy().astype(np.int64) if hashed else np.zeros((0, 8), np.int64)),
+             idx_level_last=hg.tcnn_corner_indices(x, meta, L - 1).numpy().astype(np.int64),
+             offsets=np.array(meta.offsets), resolutions=np.array(meta.resolutions), scales=np.array(meta.scales, dtype=np.float32))
+    # nerfstudio torch layout at the reference's size (R:lse_nerf/lse_field.py:43-65: L = 16, T = 2^19, 16 -> 2048): the 67 MB table is
+    # regenerated from the seed (init_torch_table), the 4096 points are stored
+    g = gen(SEED + 1619)
+    meta = hg.torch_grid_meta(16, 16, 2048, 19, 2)
+    table = hg.init_torch_table(meta, generator=g)
+    x = torch.rand(BIG_N, 3, generator=g)
+    y = hg.hash_encode_torch(x, table, meta).double().reshape(BIG_N, 16, 2)
+    save(f"hash_torch_L16_T19_n{BIG_N}", seed=SEED + 1619, n=BIG_N, stride=BIG_STRIDE, x=x.numpy(), table_checksum=bits_checksum(table.numpy()),
+         y_rows=y.float().reshape(BIG_N, 32)[::BIG_STRIDE].numpy(), y_level_sums=y.sum(dim=(0, 2)).numpy(),
+         y_level_abs_sums=y.abs().sum(dim=(0, 2)).numpy(), scalings=meta.scalings.numpy())
+
+
 def make_mlp():
     for name, (i, layers, w, o, act) in {"base": (32, 2, 64, 16, None), "head": (63, 3, 64, 3, "Sigmoid")}.items():
         g = gen(SEED + len(name))
@@ -174,7 +216,10 @@ def make_config1():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    make_hash(); make_mlp(); make_sh(); make_traverse(); make_volrend(); make_grid_update(); make_config1()
+    if "--only-big-hash" in sys.argv:          # (round 5: the 4096-point fixtures were added without rewriting the older files)
+        make_hash_big()
+    else:
+        make_hash(); make_hash_big(); make_mlp(); make_sh(); make_traverse(); make_volrend(); make_grid_update(); make_config1()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f"{f:40s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KB")

@@ -36,6 +36,51 @@ def test_golden_hash_tcnn(L, T):
     assert np.array_equal(hg.tcnn_corner_indices(x, meta, L - 1).numpy(), z["idx_level_last"])
 
 
+@pytest.mark.parametrize("L,T", list(mg.BIG_HASH))
+def test_golden_hash_tcnn_4096_points(L, T):
+    """SURVEY 8c (i) at its stated size: 4096 points, incl. the production table size T = 2^19 (the table is regenerated from the
+    stored seed; outputs are stored as every-8th row + per-level sums, tests/golden/README.md)."""
+    z = gold(f"hash_tcnn_L{L}_T{T}_n4096")
+    meta, table, x, w = mg.hash_inputs(L, T, int(z["n"]), int(z["seed"]))
+    assert np.array_equal(x.numpy(), z["x"]) and mg.bits_checksum(table.numpy()) == z["table_checksum"]
+    assert mg.bits_checksum(w.numpy()) == z["w_checksum"]
+    assert list(z["offsets"]) == meta.offsets and list(z["resolutions"]) == meta.resolutions
+    tc, xc = table.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = hg.hash_encode_tcnn(xc, tc, meta)
+    (y * w).sum().backward()
+    st = int(z["stride"])
+    assert np.allclose(y.detach()[::st].numpy(), z["y_rows"], rtol=1e-6, atol=1e-8)
+    yd = y.detach().double().reshape(-1, L, 2)
+    assert np.allclose(yd.sum(dim=(0, 2)).numpy(), z["y_level_sums"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(yd.abs().sum(dim=(0, 2)).numpy(), z["y_level_abs_sums"], rtol=1e-9)
+    assert np.allclose(xc.grad.numpy(), z["dx"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(mg.level_sums(tc.grad, meta, L), z["dtable_level_sums"], rtol=1e-7, atol=1e-7)
+    assert np.allclose(mg.level_sums(tc.grad, meta, L, True), z["dtable_level_abs_sums"], rtol=1e-7)
+    assert np.allclose(tc.grad[:4096].numpy(), z["dtable_head"], rtol=1e-5, atol=1e-7)
+    fh = int(z["first_hashed_level"])
+    if fh >= 0:
+        assert not meta.is_dense(fh) and (fh == 0 or meta.is_dense(fh - 1))
+        assert np.array_equal(hg.tcnn_corner_indices(x, meta, fh).numpy(), z["idx_first_hashed"])
+    assert np.array_equal(hg.tcnn_corner_indices(x, meta, L - 1).numpy(), z["idx_level_last"])
+
+
+def test_golden_hash_torch_layout_at_the_references_size():
+    """nerfstudio's torch layout at L = 16 / T = 2^19 / 16 -> 2048 (R:lse_nerf/lse_field.py:43-65), 4096 points; the 67 MB table is
+    regenerated from the seed."""
+    z = gold("hash_torch_L16_T19_n4096")
+    g = mg.gen(int(z["seed"]))
+    meta = hg.torch_grid_meta(16, 16, 2048, 19, 2)
+    table = hg.init_torch_table(meta, generator=g)
+    x = torch.rand(int(z["n"]), 3, generator=g)
+    assert np.array_equal(x.numpy(), z["x"]) and mg.bits_checksum(table.numpy()) == z["table_checksum"]
+    assert np.array_equal(meta.scalings.numpy(), z["scalings"]) and float(meta.scalings[-1]) == 2047.0     # (f32 growth: not 2048)
+    y = hg.hash_encode_torch(x, table, meta)
+    assert np.allclose(y[::int(z["stride"])].numpy(), z["y_rows"], rtol=1e-6, atol=1e-10)
+    yd = y.double().reshape(-1, 16, 2)
+    assert np.allclose(yd.sum(dim=(0, 2)).numpy(), z["y_level_sums"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(yd.abs().sum(dim=(0, 2)).numpy(), z["y_level_abs_sums"], rtol=1e-9)
+
+
 def test_golden_hash_torch_layout():
     z = gold("hash_torch_L4_T10")
     meta = hg.torch_grid_meta(4, 16, 128, 10, 2)
