@@ -14,8 +14,14 @@
  *   - tensors are dense row-major fp32 unless stated; sizes are element counts;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it and
  *     nothing synchronises: callers own ordering, memory and lifetime (no allocation inside the library);
- *   - return value: 0 = OK, <0 = error (LSE_E_*), message via lse_last_error() (thread-local);
- *   - functions marked "accumulate" add into their output (callers zero it), others overwrite.
+ *   - return value: 0 = OK, <0 = error (LSE_E_*), message via lse_last_error();
+ *   - functions marked "accumulate" add into their output (callers zero it), others overwrite;
+ *   - NO GLOBAL OR THREAD-LOCAL STATE (ABI 5): every entry point is a function of its arguments alone -- what a call does never
+ *     depends on an earlier call.  Kernel variants, arithmetic conventions and device-side sample counts are call arguments
+ *     (lse_hash_bwd_opts, lse_mlp_desc.arith, `flags`, `n_dev`); there is nothing to set, reset or bracket, and any number of
+ *     host threads may call concurrently on their own streams.  The one thread-local datum is the MESSAGE of the calling thread's
+ *     last failed call (lse_last_error): written by a failing call, never read by the library.  The tuning knobs of the
+ *     development build (csrc/dev_knobs.h, `make dev` -> liblse_hip_dev.so) are not part of this library.
  */
 #ifndef LSE_HIP_H
 #define LSE_HIP_H
@@ -26,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LSE_ABI_VERSION 4
+#define LSE_ABI_VERSION 5
 
 #define LSE_OK 0
 #define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
@@ -70,7 +76,15 @@ typedef struct lse_mlp_desc {
      * mask 1): its per-sample input h[N,16] = [density logit | 15 geometry features] meets columns 16..30 of tcnn's
      * [width x 64] input matrix in place (R:lse_nerf/lse_field.py:254-262, :347-356) -- no per-step split copy. */
     int32_t w0_ld, w0_col, w0_mask_col0;
+    /* arithmetic route of the FORWARD where two are built (width 64 with 16 row-major or 32 inputs): LSE_MLP_ARITH_AUTO = the
+     * bf16-piece kernels (f32 operands cut into three bf16 pieces, six piece products per multiply on the bf16 matrix cores, f32
+     * accumulate: the f32 error bound, csrc/mlp_x6.h); LSE_MLP_ARITH_F32_MFMA = v_mfma_f32_16x16x4_f32 (what every other shape
+     * runs on).  The two routes differ in the last bits, both within f32 rounding of the exact result.  The backward's route
+     * follows act_tiled (3 = bf16 pieces). */
+    int32_t arith;
 } lse_mlp_desc;
+#define LSE_MLP_ARITH_AUTO 0
+#define LSE_MLP_ARITH_F32_MFMA 1
 
 /* ---- misc -------------------------------------------------------------------------------------------- */
 int lse_abi_version(void);
@@ -80,12 +94,17 @@ const char *lse_last_error(void);
  *      R:lse_nerf/lse_grid_estimator.py:93-106.  Two passes like the upstream kernel:
  *      mode 0 fills chunk_cnts[R]; mode 1 reads chunk_starts[R] and writes the packed samples.
  *      binaries [levels, rx, ry, rz] uint8; aabbs [levels, 6]; near/far per ray.  Integer outputs are
- *      bit-exact against oracle/c/lse_oracle.c.  ------------------------------------------------------ */
+ *      bit-exact against oracle/c/lse_oracle.c.
+ *      flags: 0 = every product and sum of the traversal set-up rounded separately (bit-exact against
+ *      oracle/c/liblse_oracle.so); LSE_TRAVERSE_FMA_SETUP = the a*b+c sites of nerfacc's grid.cu (ray start / end, the two
+ *      products of tmax_xyz) as fused multiply-adds -- what nvcc's default contraction emits -- bit-exact against
+ *      liblse_oracle_fma.so.  The two conventions differ in about one sample interval per million. ------------ */
+#define LSE_TRAVERSE_FMA_SETUP 1
 int lse_traverse_grids(const float *rays_o, const float *rays_d, int32_t n_rays, const uint8_t *binaries,
                        const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
                        const float *near_planes, const float *far_planes, float step_size, float cone_angle,
                        int32_t mode, int64_t *chunk_cnts, const int64_t *chunk_starts, int32_t *ray_indices,
-                       float *t_starts, float *t_ends, lse_stream_t stream);
+                       float *t_starts, float *t_ends, int32_t flags, lse_stream_t stream);
 
 /* Single-pass variant of the same traversal (same arithmetic, same samples): ray r writes its (t_start, t_end) pairs into
  * the fixed-capacity slots [r*cap, (r+1)*cap) and its count into chunk_cnts[r]; *overflow is OR-ed with 1 if a ray
@@ -96,7 +115,7 @@ int lse_traverse_grids_slots(const float *rays_o, const float *rays_d, int32_t n
                              const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
                              const float *near_planes, const float *far_planes, float step_size, float cone_angle,
                              int64_t cap, int64_t *chunk_cnts, float *t_start_slots, float *t_end_slots,
-                             int32_t *overflow, lse_stream_t stream);
+                             int32_t *overflow, int32_t flags, lse_stream_t stream);
 int lse_compact_ray_slots(const float *t_start_slots, const float *t_end_slots, int64_t cap, const int64_t *packed_info,
                           int32_t n_rays, int32_t *ray_indices, float *t_starts, float *t_ends, lse_stream_t stream);
 
@@ -149,33 +168,42 @@ int lse_compact_samples(const uint8_t *mask, const int64_t *packed_info, const i
 
 /* ---- field ------------------------------------------------------------------------------------------- */
 
+/* Device-side sample count `n_dev` (nullable) of the PER-SAMPLE entry points
+ *     lse_positions_fwd / _bwd, lse_hash_fwd, lse_hash_bwd / _levels / _ex, lse_mlp_fwd / _bwd.
+ * The sampler knows the number of packed samples only on the device (lse_pack_info_from_counts); reading it back costs a host
+ * synchronisation per sampler call, twice per step with the visibility pre-pass.  With n_dev != NULL the `n` argument is a
+ * CAPACITY -- buffer extents, level strides and the launch grid are sized by it -- and every kernel clamps it to the int64 that
+ * n_dev addresses when it starts; workgroups past the count leave at once.  Nothing at or beyond the count is read or written.
+ * The per-ray entry points (visibility, compaction, volume rendering, ray reductions) take their counts from packed_info.
+ * (Until ABI 4 this pointer was ambient per-thread state, lse_set_device_count.) */
+
 /* R:lse_nerf/lse_field.py:266-274: pos = o[ri] + d[ri]*(ts+te)/2 -> L-inf contraction -> (x+2)/4 (contraction=1)
  * or aabb normalisation (contraction=0, h_aabb[6]) -> selector -> x*selector.  ray_idx==NULL: rays_o holds N
  * positions directly (Field.density_fn). */
 int lse_positions_fwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
-                      const float *t_ends, int64_t n, int32_t contraction, const float *h_aabb, float *x01,
-                      uint8_t *selector, lse_stream_t stream);
+                      const float *t_ends, int64_t n, const int64_t *n_dev, int32_t contraction, const float *h_aabb,
+                      float *x01, uint8_t *selector, lse_stream_t stream);
 /* d(pos)[N,3] from d(x01)[N,3] (Jacobian of contraction/normalisation, selector-masked). */
 int lse_positions_bwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
-                      const float *t_ends, int64_t n, int32_t contraction, const float *h_aabb, const float *d_x01,
-                      float *d_pos, lse_stream_t stream);
+                      const float *t_ends, int64_t n, const int64_t *n_dev, int32_t contraction, const float *h_aabb,
+                      const float *d_x01, float *d_pos, lse_stream_t stream);
 /* per-ray sums: d_o[r] = sum d_pos, d_d[r] = sum d_pos*(ts+te)/2 over the ray's packed samples. */
 int lse_ray_grad_reduce(const float *d_pos, const float *t_starts, const float *t_ends, const int64_t *packed_info,
                         int32_t n_rays, float *d_rays_o, float *d_rays_d, lse_stream_t stream);
 
 /* tcnn kernel_grid forward (R:lse_nerf/lse_field.py:279 via HashEncoding.forward): x01[N,3] -> y[L][N][F]. */
 int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const float *table, float *y, int64_t n,
-                 lse_stream_t stream);
+                 const int64_t *n_dev, lse_stream_t stream);
 /* tcnn kernel_grid_backward (+_input): dtable accumulate (float atomics); dx[N,3] overwritten (NULL: skip). */
 int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
-                 float *dx, int64_t n, lse_stream_t stream);
+                 float *dx, int64_t n, const int64_t *n_dev, lse_stream_t stream);
 
 /* The same backward restricted to levels [level_begin, level_end); dx_accumulate != 0 adds this launch's share to dx.
  * Lets the caller finish the fine levels' table gradients (most of the bytes) first and start their all-reduce while
  * the remaining levels are still being computed (lsenerf_amd.dist.OverlappedGradExchange). */
 int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                         float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end,
-                        int64_t n, lse_stream_t stream);
+                        int64_t n, const int64_t *n_dev, lse_stream_t stream);
 
 /* Kernel selection of the hash backward as CALL ARGUMENTS (so that two variants can be compared inside one process):
  *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
@@ -188,7 +216,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
  *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
- *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3, run-time option "hash_bwd_probes")
+ *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)
  *   coarse_levels the levels below this one are processed first by a cache-free kernel at high occupancy (lane = sample, run
@@ -219,45 +247,10 @@ void lse_hash_bwd_default_opts(lse_hash_bwd_opts *opts);
 int64_t lse_hash_bwd_workspace_bytes(const lse_grid_desc *desc, const lse_hash_bwd_opts *opts);
 int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table, float *dtable,
                     float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end, int64_t n,
-                    const lse_hash_bwd_opts *opts /* NULL = defaults */, lse_stream_t stream);
+                    const int64_t *n_dev, const lse_hash_bwd_opts *opts /* NULL = defaults */, lse_stream_t stream);
 
-/* Development knobs that are not part of any call signature, readable and writable at run time (no environment
- * variables are consulted after the library is loaded):
- *   "hash_fwd_mapping"  workgroup -> (level, chunk) order of lse_hash_fwd: 4 = level-major, finest level first (default),
- *                       3 = level-major coarse first, 0 / 1 = XCD-bound levels, 2 = level-interleaved
- *   "mlp_fwd_cfg" / "mlp_bwd_cfg"  CT * 10 + NW tile shape of the fused MLP kernels (default 28)
- *   "mlp_fwd_impl"      2 = third-generation fused forward where it is built (width 64, 16 row-major or 32 inputs; default):
- *                       f32 operands cut into three bf16 pieces, six piece products per multiply on the bf16 matrix cores,
- *                       f32 accumulate -- the f32 error bound (csrc/mlp_x6.h); 1 = f32-MFMA forward (second generation:
- *                       contiguous tiles per wave, 4 waves per SIMD), 0 = first generation.  The values of the two
- *                       arithmetic routes differ in the last bits (both within f32 rounding of the exact result)
- *   "mlp_bwd_impl"      1 = second-generation fused backward (contiguous tiles per wave, bias gradient inside the dW0
- *                       MFMAs; default), 0 = first-generation kernel
- *   "mlp_bwd3_cfg"      CT * 100 + NW of the third-generation fused backward (default 208; 112, 108, 204 = A/B partners)
- *   "hash_bwd_probes" / "hash_bwd_few_runs" / "hash_bwd_stage_max"   defaults of lse_hash_bwd_opts.second_probe (3: probe rounds of
- *                       the backward's sector cache), .few_runs (6) and .stage_max (16), for A/B runs of whole steps
- *   "traverse_vec"      1 = 64-steps-at-once marcher for constant step sizes (default, bit-identical), 0 = serial loop only
- *   "traverse_fma"      0 (default) = every product and sum of the traversal set-up rounded separately (bit-exact against
- *                       oracle/c/liblse_oracle.so); 1 = the a*b+c sites of nerfacc's grid.cu (ray start / end, the two products of
- *                       tmax_xyz) as fused multiply-adds -- what nvcc's default contraction emits -- bit-exact against
- *                       liblse_oracle_fma.so.  The two settings differ in about one sample interval per million
- * Returns LSE_E_INVALID for an unknown name.  Integer outputs never depend on these; floating-point results agree within
- * rounding (mlp_fwd_impl chooses between two arithmetic routes of the same accuracy, the rest only reorder launches). */
-int lse_set_option(const char *name, int64_t value);
-int lse_get_option(const char *name, int64_t *value);
-
-/* Device-side sample count.  The sampler knows the number of packed samples only on the device (lse_pack_info_from_counts);
- * reading it back costs a host synchronisation per sampler call, twice per step with the visibility pre-pass.  With a non-NULL
- * pointer set here (per calling thread, until reset with NULL), the PER-SAMPLE entry points
- *     lse_positions_fwd / _bwd, lse_hash_fwd, lse_hash_bwd / _levels / _ex (impl 2), lse_mlp_fwd / _bwd
- * treat their `n` argument as a CAPACITY -- buffer extents, level strides and the launch grid are sized by it -- and every kernel
- * clamps it to the int64 the pointer addresses when it starts; workgroups past the count leave at once.  Nothing at or beyond
- * the count is read or written.  The per-ray entry points (visibility, compaction, volume rendering, ray reductions) take
- * their counts from packed_info and need nothing.  lse_density_fwd / _bwd and the unfused lse_mlp_wgrad reject a set pointer. */
-int lse_set_device_count(const int64_t *n_dev);
-
-/* fused MLP forward on the matrix cores (f32 MFMA, or bf16 MFMA on three-piece operands with the same error bound: option
- * "mlp_fwd_impl").  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
+/* fused MLP forward on the matrix cores (f32 MFMA, or bf16 MFMA on three-piece operands with the same error bound:
+ * lse_mlp_desc.arith).  row_bias[R,width] (nullable) is added to layer-0 pre-activations of sample i
  * from row row_bias_idx[i].  act (nullable) receives the post-ReLU hidden activations: act_tiled = 0 -> row-major
  * [n_hidden_layers][N][width] (what lse_mlp_wgrad reads); act_tiled = 1 -> tile-major, an opaque workspace of
  * n_hidden_layers * roundup(N,16) * width floats that only lse_mlp_bwd (same act_tiled) understands; act_tiled = 2 (two
@@ -272,7 +265,8 @@ int lse_set_device_count(const int64_t *n_dev);
  * R:lse_nerf/lse_field.py:286-287); selector nullable. */
 int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
                 const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, int32_t act_tiled,
-                float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream);
+                float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, const int64_t *n_dev,
+                lse_stream_t stream);
 /* backward: d_out[N,out_cols] (w.r.t. the activated output) -> d_in (layout of desc->in_layout; nullable) and, when
  * d_params is given, the weight gradients of every layer accumulated into d_params (same layout as params) in the
  * same pass (`in` = the layer-0 input is then required).  d_sigma (nullable): gradient of the fused density head, folded
@@ -283,7 +277,8 @@ int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, 
 int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *act, int32_t act_tiled,
                 const float *out, int32_t out_cols, const float *d_out, const float *d_sigma, const uint8_t *selector, float density_scale,
                 float *d_out_pre, float *d_act, float *d_act0, float *d_in, float *d_params,
-                const float *row_bias, const int32_t *row_bias_idx, float *d_row_bias, int64_t n, lse_stream_t stream);
+                const float *row_bias, const int32_t *row_bias_idx, float *d_row_bias, int64_t n, const int64_t *n_dev,
+                lse_stream_t stream);
 /* unfused weight gradients from materialised d_act / d_out_pre, accumulate into d_params (same layout as params). */
 int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const float *act, const float *d_act,
                   const float *d_out_pre, float *d_params, int64_t n, lse_stream_t stream);
@@ -397,17 +392,18 @@ int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, c
 /* ---- optimiser: torch.optim.Adam semantics on a flat buffer (R:lse_nerf/lse_config.py:29-33) ----------- */
 int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, lse_stream_t stream);
-/* The same with the step-dependent scalars in device memory: hyper[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)}.  A launch
- * captured into a HIP graph cannot carry new scalar arguments; lse_adam_schedule_dev (captured in front of it) derives them. */
+/* The same with EVERY scalar of the step in device memory: hyper[6] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step), beta1, beta2,
+ * eps}.  A launch captured into a HIP graph cannot carry new scalar arguments; lse_adam_schedule_dev (captured in front of it)
+ * writes all six. */
 int lse_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *hyper,
-                      float beta1, float beta2, float eps, float grad_scale, lse_stream_t stream);
-/* Device-side optimizer clock (ABI 4): *step (optimizer steps taken so far, int64 in device memory) is advanced by one and
- * hyper[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} of the NEW step is written, with nerfstudio's
- * ExponentialDecayScheduler lr = lr_init * (lr_final / lr_init)^(min(steps taken / max_steps, 1)) (max_steps <= 0 or
- * lr_final <= 0: constant lr_init; R:lse_nerf/lse_config.py:29-38).  Replaces the per-step host -> device copy of the three
- * scalars: a replayed graph depends on nothing the host writes, however far the host runs ahead. */
-int lse_adam_schedule_dev(int64_t *step, float *hyper, double lr_init, double lr_final, int64_t max_steps, double beta1,
-                          double beta2, lse_stream_t stream);
+                      float grad_scale, lse_stream_t stream);
+/* Device-side optimizer clock: *step (optimizer steps taken so far, int64 in device memory) is advanced by one and hyper[6] of
+ * the NEW step is written, with nerfstudio's ExponentialDecayScheduler lr = lr_init * (lr_final / lr_init)^(min(steps taken /
+ * max_steps, 1)) (max_steps <= 0 or lr_final <= 0: constant lr_init; R:lse_nerf/lse_config.py:29-38).  The schedule's constants
+ * are read from device memory too -- sched[6] = {lr_init, lr_final, max_steps, beta1, beta2, eps} as doubles (ABI 5; they were
+ * launch arguments, frozen into a captured graph) -- so a replayed graph depends on nothing the host writes per step, however far
+ * the host runs ahead, and follows a changed learning-rate schedule without being captured again. */
+int lse_adam_schedule_dev(int64_t *step, float *hyper, const double *sched, lse_stream_t stream);
 
 #ifdef __cplusplus
 }

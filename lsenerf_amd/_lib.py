@@ -11,12 +11,17 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSE_HIP_LIB", os.path.join(_HERE, "liblse_hip.so"))   # override: A/B builds of the same ABI
+# the development build (make -C lsenerf_amd/csrc dev): same ABI + the tuning knobs of csrc/dev_knobs.h and the superseded kernel
+# variants.  Never loaded by the product path: tools/ and the variant tests switch to it explicitly (dev_library()).
+DEV_LIB_PATH = os.environ.get("LSE_HIP_DEV_LIB", os.path.join(_HERE, "liblse_hip_dev.so"))
 
 LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
 LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
 LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
-LSE_ABI_VERSION = 4
+LSE_ABI_VERSION = 5
+LSE_MLP_ARITH_AUTO, LSE_MLP_ARITH_F32_MFMA = 0, 1
+LSE_TRAVERSE_FMA_SETUP = 1
 
 
 class GridDesc(Structure):
@@ -42,7 +47,7 @@ LSE_ONE_DIM_NONE, LSE_ONE_DIM_LEARNED, LSE_ONE_DIM_GRAY = 0, 1, 2
 
 class MlpDesc(Structure):
     _fields_ = [("n_in", c_int32), ("width", c_int32), ("n_hidden_layers", c_int32), ("out_activation", c_int32),
-                ("in_layout", c_int32), ("w0_ld", c_int32), ("w0_col", c_int32), ("w0_mask_col0", c_int32)]
+                ("in_layout", c_int32), ("w0_ld", c_int32), ("w0_col", c_int32), ("w0_mask_col0", c_int32), ("arith", c_int32)]
 
 
 P = c_void_p
@@ -50,8 +55,8 @@ I32, I64, F32 = c_int32, c_int64, c_float
 
 # name -> argtypes (all return int except the two misc functions); mirrors include/lse_hip.h one to one
 SIGNATURES = {
-    "lse_traverse_grids": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I32, P, P, P, P, P, P],
-    "lse_traverse_grids_slots": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I64, P, P, P, P, P],
+    "lse_traverse_grids": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I32, P, P, P, P, P, I32, P],
+    "lse_traverse_grids_slots": [P, P, I32, P, P, I32, I32, I32, I32, P, P, F32, F32, I64, P, P, P, P, I32, P],
     "lse_compact_ray_slots": [P, P, I64, P, I32, P, P, P, P],
     "lse_pack_info_from_counts": [P, I32, P, P, P],
     "lse_fake_sample_if_empty": [P, I32, P, P, P, P, P, P, P, I64, I32, I32, P],
@@ -61,18 +66,15 @@ SIGNATURES = {
     "lse_visibility_mask_cap": [P, P, P, P, I32, F32, F32, P, P, P, P],
     "lse_compact_samples": [P, P, P, I32, P, P, P, P, P, P, P],
     "lse_compact_features": [P, P, P, I32, P, P, P, I32, I64, I64, P, P, P, P],
-    "lse_positions_fwd": [P, P, P, P, P, I64, I32, P, P, P, P],
-    "lse_positions_bwd": [P, P, P, P, P, I64, I32, P, P, P, P],
+    "lse_positions_fwd": [P, P, P, P, P, I64, P, I32, P, P, P, P],
+    "lse_positions_bwd": [P, P, P, P, P, I64, P, I32, P, P, P, P],
     "lse_ray_grad_reduce": [P, P, P, P, I32, P, P, P],
-    "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P],
-    "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P],
-    "lse_hash_bwd_levels": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P],
-    "lse_hash_bwd_ex": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, POINTER(HashBwdOpts), P],
-    "lse_set_option": [c_char_p, I64],
-    "lse_set_device_count": [P],
-    "lse_get_option": [c_char_p, POINTER(c_int64)],
-    "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P],
-    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, P, I64, P],
+    "lse_hash_fwd": [POINTER(GridDesc), P, P, P, I64, P, P],
+    "lse_hash_bwd": [POINTER(GridDesc), P, P, P, P, P, I64, P, P],
+    "lse_hash_bwd_levels": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P, P],
+    "lse_hash_bwd_ex": [POINTER(GridDesc), P, P, P, P, P, I32, I32, I32, I64, P, POINTER(HashBwdOpts), P],
+    "lse_mlp_fwd": [POINTER(MlpDesc), P, P, P, P, P, I32, P, I32, P, P, F32, I64, P, P],
+    "lse_mlp_bwd": [POINTER(MlpDesc), P, P, P, I32, P, I32, P, P, P, F32, P, P, P, P, P, P, P, P, I64, P, P],
     "lse_mlp_wgrad": [POINTER(MlpDesc), P, P, P, P, P, I64, P],
     "lse_segment_sum_rows": [P, I32, P, I32, P, P],
     "lse_ray_features_fwd": [P, P, P, I32, I32, P, P],
@@ -94,32 +96,35 @@ SIGNATURES = {
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],
-    "lse_adam_step_dev": [P, P, P, P, I64, P, F32, F32, F32, F32, P],
-    "lse_adam_schedule_dev": [P, P, c_double, c_double, I64, c_double, c_double, P],
+    "lse_adam_step_dev": [P, P, P, P, I64, P, F32, P],
+    "lse_adam_schedule_dev": [P, P, P, P],
+}
+# exported by the development build only (csrc/dev_knobs.h)
+DEV_SIGNATURES = {
+    "lse_set_option": [c_char_p, I64],
+    "lse_get_option": [c_char_p, POINTER(c_int64)],
 }
 
 _lib = None
+_prod_lib = None       # the library that ships, while dev_library() has swapped the development build in
+_dev_lib = None
 
 
 class LseHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load liblse_hip.so (built by ``__graft_entry__.build()`` / ``make -C lsenerf_amd/csrc``)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str, what: str, extra: dict):
+    if not os.path.exists(path):
         raise LseHipError(
-            f"{LIB_PATH} not found: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; "
-            f"g.build()'` or `make -C lsenerf_amd/csrc`).  There is no CPU fallback for the product path.")
-    lib = ctypes.CDLL(LIB_PATH)
+            f"{path} not found: {what} has not been built (run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C lsenerf_amd/csrc all dev`).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(path)
     lib.lse_last_error.restype = c_char_p
     lib.lse_last_error.argtypes = []
     lib.lse_abi_version.restype = c_int32
     lib.lse_abi_version.argtypes = []
-    for name, argtypes in SIGNATURES.items():
+    for name, argtypes in {**SIGNATURES, **extra}.items():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = c_int32
@@ -129,15 +134,63 @@ def load():
     lib.lse_hash_bwd_workspace_bytes.argtypes = [POINTER(GridDesc), POINTER(HashBwdOpts)]
     v = lib.lse_abi_version()
     if v != LSE_ABI_VERSION:
-        raise LseHipError(f"liblse_hip.so ABI version {v} != binding version {LSE_ABI_VERSION}")
-    _lib = lib
-    # developer convenience for A/B scripts: LSE_OPT_<NAME>=<int> seeds the library's run-time options once, here on the
-    # Python side (the library itself reads no environment variables)
-    for k, val in os.environ.items():
-        if k.startswith("LSE_OPT_"):
-            if lib.lse_set_option(k[len("LSE_OPT_"):].lower().encode(), int(val)) != 0:
-                raise LseHipError(f"{k}: {lib.lse_last_error().decode()}")
+        raise LseHipError(f"{os.path.basename(path)} ABI version {v} != binding version {LSE_ABI_VERSION}")
     return lib
+
+
+def load():
+    """Load liblse_hip.so (built by ``__graft_entry__.build()`` / ``make -C lsenerf_amd/csrc``).  ``LSE_DEV=1`` in the environment
+    makes the development build the process's library from the start (A/B tools; ``LSE_OPT_<NAME>=<int>`` then seeds its knobs)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if os.environ.get("LSE_DEV", "0") not in ("", "0"):
+        _lib = _load_dev()
+        for k, val in os.environ.items():
+            if k.startswith("LSE_OPT_"):
+                if _lib.lse_set_option(k[len("LSE_OPT_"):].lower().encode(), int(val)) != 0:
+                    raise LseHipError(f"{k}: {_lib.lse_last_error().decode()}")
+        return _lib
+    _lib = _open(LIB_PATH, "the HIP extension", {})
+    return _lib
+
+
+def _load_dev():
+    global _dev_lib
+    if _dev_lib is None:
+        _dev_lib = _open(DEV_LIB_PATH, "the development build of the HIP extension", DEV_SIGNATURES)
+    return _dev_lib
+
+
+def dev_available() -> bool:
+    return os.path.exists(DEV_LIB_PATH)
+
+
+class dev_library:
+    """``with _lib.dev_library(): ...`` -- every C-ABI call inside the block goes to the DEVELOPMENT build (liblse_hip_dev.so: same
+    entry points + the tuning knobs and superseded kernel variants of csrc/dev_knobs.h).  For tools and variant tests only; knobs
+    changed inside the block are restored on exit."""
+
+    def __enter__(self):
+        global _lib, _prod_lib
+        load()
+        self._outer = _lib
+        dev = _load_dev()
+        self._saved = {}
+        _prod_lib, _lib = (_prod_lib or self._outer), dev
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        for name, v in self._saved.items():
+            _load_dev().lse_set_option(name.encode(), v)
+        _lib = self._outer
+        return False
+
+    def set_option(self, name: str, value: int) -> None:
+        if name not in self._saved:
+            self._saved[name] = get_option(name)
+        set_option(name, value)
 
 
 # bench.py sets this to {"names": set or None (= every entry point), "events": []}: those entry points are then bracketed by HIP events
@@ -166,12 +219,22 @@ def call(name: str, *args):
         raise LseHipError(f"{name} failed (rc={rc}): {lib.lse_last_error().decode()}")
 
 
+def _dev_active():
+    lib = load()
+    if not hasattr(lib, "lse_set_option") or lib is not _dev_lib:
+        raise LseHipError("tuning knobs exist in the development build only (csrc/dev_knobs.h): use `with _lib.dev_library():` "
+                          "or LSE_DEV=1; liblse_hip.so has no state to set")
+    return lib
+
+
 def set_option(name: str, value: int) -> None:
-    """Run-time development knob of the library (include/lse_hip.h: lse_set_option); speed only, never results."""
+    """Tuning knob of the DEVELOPMENT build (csrc/dev_knobs.h); speed only, never results."""
+    _dev_active()
     call("lse_set_option", name.encode(), int(value))
 
 
 def get_option(name: str) -> int:
+    _dev_active()
     v = c_int64(0)
     call("lse_get_option", name.encode(), ctypes.byref(v))
     return int(v.value)

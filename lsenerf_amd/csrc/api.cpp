@@ -1,9 +1,10 @@
-// Error reporting + version of the C-ABI (include/lse_hip.h).
+// Error reporting + version of the C-ABI (include/lse_hip.h), and the tuning knobs of the DEVELOPMENT build.
 #include "common.h"
 #include <string.h>
 #include <atomic>
 
 namespace lse {
+// the calling thread's last error MESSAGE: written by a failing call, never read by the library (lse_last_error hands it out)
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -13,38 +14,53 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-}  // namespace lse
 
-namespace lse {
-// run-time development knobs (include/lse_hip.h: lse_set_option); plain ints, read at every launch
-struct Option { const char *name; std::atomic<int64_t> value; };
-static Option g_options[] = {
-    {"hash_fwd_mapping", {4}},
-    {"hash_fwd_lds_levels", {0}},
-    {"compact_features_groups", {4}},
-    {"mlp_fwd_cfg", {28}},
-    {"mlp_bwd_cfg", {28}},
-    {"mlp_bwd_impl", {1}},
-    {"mlp_fwd_impl", {2}},
-    {"mlp_bwd3_cfg", {208}},
-    {"mlp_act_nt", {0}},
-    {"hash_bwd_probes", {3}},
-    {"hash_bwd_few_runs", {6}},
-    {"hash_bwd_stage_max", {16}},
-    {"traverse_vec", {1}},
-    {"traverse_fma", {0}},
+// Tuning knobs.  In the library that ships (liblse_hip.so) they are CONSTANTS: `option()` is a lookup in a read-only table and
+// nothing can change a value -- the library has no state.  The development build (make dev -> liblse_hip_dev.so,
+// -DLSE_DEV_KNOBS, csrc/dev_knobs.h) makes the same table writable through lse_set_option for A/B runs of whole steps.
+struct Option {
+    const char *name;
+#ifdef LSE_DEV_KNOBS
+    std::atomic<int64_t> value;
+#else
+    int64_t value;
+#endif
 };
-static thread_local const int64_t *g_device_count = nullptr;
-const int64_t *device_count() { return g_device_count; }
+#ifdef LSE_DEV_KNOBS
+static Option g_options[] = {
+#else
+static const Option g_options[] = {
+#endif
+    {"hash_fwd_mapping", 4},
+    {"hash_fwd_lds_levels", 0},
+    {"compact_features_groups", 4},
+    {"mlp_fwd_cfg", 28},
+    {"mlp_bwd_cfg", 28},
+    {"mlp_bwd_impl", 1},
+    {"mlp_bwd3_cfg", 208},
+    {"mlp_act_nt", 0},
+    {"hash_bwd_probes", 3},
+    {"hash_bwd_few_runs", 6},
+    {"hash_bwd_stage_max", 16},
+    {"traverse_vec", 1},
+};
 
 int64_t option(const char *name)
 {
     for (auto &o : g_options)
-        if (!strcmp(o.name, name)) return o.value.load(std::memory_order_relaxed);
+        if (!strcmp(o.name, name)) {
+#ifdef LSE_DEV_KNOBS
+            return o.value.load(std::memory_order_relaxed);
+#else
+            return o.value;
+#endif
+        }
     return 0;
 }
 }  // namespace lse
 
+#ifdef LSE_DEV_KNOBS
+#include "dev_knobs.h"
 extern "C" int lse_set_option(const char *name, int64_t value)
 {
     LSE_REQUIRE(name, "lse_set_option: null name");
@@ -55,12 +71,6 @@ extern "C" int lse_set_option(const char *name, int64_t value)
         }
     lse::set_error("lse_set_option: unknown option '%s'", name);
     return LSE_E_INVALID;
-}
-
-extern "C" int lse_set_device_count(const int64_t *n_dev)
-{
-    lse::g_device_count = n_dev;
-    return LSE_OK;
 }
 
 extern "C" int lse_get_option(const char *name, int64_t *value)
@@ -74,6 +84,7 @@ extern "C" int lse_get_option(const char *name, int64_t *value)
     lse::set_error("lse_get_option: unknown option '%s'", name);
     return LSE_E_INVALID;
 }
+#endif
 
 extern "C" const char *lse_last_error(void) { return lse::g_err; }
 extern "C" int lse_abi_version(void) { return LSE_ABI_VERSION; }

@@ -10,10 +10,8 @@
 namespace lse {
 
 void set_error(const char *fmt, ...);
-int64_t option(const char *name);   // run-time development knob (lse_set_option), 0 for unknown names
-// lse_set_device_count: when non-null, the per-sample entry points hand this pointer to their kernels, which clamp the
-// host-side sample count (a CAPACITY then) to the int64 it points to -- the count never has to visit the host
-const int64_t *device_count();
+// tuning knob by name (api.cpp): a constant in the library that ships, writable in the development build only; 0 for unknown names
+int64_t option(const char *name);
 
 static inline hipStream_t as_stream(lse_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

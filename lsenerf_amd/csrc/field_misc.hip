@@ -377,8 +377,8 @@ static Box make_box(const float *h_aabb)
 }
 
 extern "C" int lse_positions_fwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx,
-                                 const float *t_starts, const float *t_ends, int64_t n, int32_t contraction,
-                                 const float *h_aabb, float *x01, uint8_t *selector, lse_stream_t stream)
+                                 const float *t_starts, const float *t_ends, int64_t n, const int64_t *n_dev,
+                                 int32_t contraction, const float *h_aabb, float *x01, uint8_t *selector, lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_positions_fwd: n < 0");
     if (n == 0) return LSE_OK;
@@ -387,13 +387,13 @@ extern "C" int lse_positions_fwd(const float *rays_o, const float *rays_d, const
     LSE_REQUIRE(contraction || h_aabb, "lse_positions_fwd: aabb normalisation needs h_aabb");
     hipLaunchKernelGGL(positions_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream),
                        rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), x01, selector,
-                       lse::device_count());
+                       n_dev);
     return lse::check_launch("lse_positions_fwd");
 }
 
 extern "C" int lse_positions_bwd(const float *rays_o, const float *rays_d, const int32_t *ray_idx,
-                                 const float *t_starts, const float *t_ends, int64_t n, int32_t contraction,
-                                 const float *h_aabb, const float *d_x01, float *d_pos, lse_stream_t stream)
+                                 const float *t_starts, const float *t_ends, int64_t n, const int64_t *n_dev,
+                                 int32_t contraction, const float *h_aabb, const float *d_x01, float *d_pos, lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_positions_bwd: n < 0");
     if (n == 0) return LSE_OK;
@@ -402,7 +402,7 @@ extern "C" int lse_positions_bwd(const float *rays_o, const float *rays_d, const
     LSE_REQUIRE(contraction || h_aabb, "lse_positions_bwd: aabb normalisation needs h_aabb");
     hipLaunchKernelGGL(positions_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream),
                        rays_o, rays_d, ray_idx, t_starts, t_ends, n, contraction, make_box(h_aabb), d_x01, d_pos,
-                       lse::device_count());
+                       n_dev);
     return lse::check_launch("lse_positions_bwd");
 }
 
@@ -422,7 +422,6 @@ extern "C" int lse_density_fwd(const float *h, const uint8_t *selector, float sc
                                lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_density_fwd: n < 0");
-    LSE_REQUIRE(!lse::device_count(), "lse_density_fwd does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(h && sigma, "lse_density_fwd: null pointer");
     hipLaunchKernelGGL(density_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream), h,
@@ -434,7 +433,6 @@ extern "C" int lse_density_bwd(const float *h, const uint8_t *selector, float sc
                                int64_t n, lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_density_bwd: n < 0");
-    LSE_REQUIRE(!lse::device_count(), "lse_density_bwd does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(h && d_sigma && d_h, "lse_density_bwd: null pointer");
     hipLaunchKernelGGL(density_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lse::as_stream(stream), h,

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(GridParams g, con
 // the 160 KB of a CU), then walks a contiguous share of the samples: positions in, 8 ds_read_b64 gathers per sample, the same
 // multiply-adds in the same order as hash_fwd_kernel (bit-identical results), y out.  Consecutive samples of a ray fall into the same
 // coarse cell, so most gathers of a wave-instruction are LDS broadcasts.
+#ifdef LSE_DEV_KNOBS   // development build only (csrc/dev_knobs.h): superseded / A-B variant, not in liblse_hip.so
 constexpr int kFwdLdsThreads = 1024;
 __global__ __launch_bounds__(kFwdLdsThreads) void hash_fwd_lds_kernel(GridParams g, int level, const float *__restrict__ x,
                                                                       const float2 *__restrict__ table, float2 *__restrict__ y,
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(kFwdLdsThreads) void hash_fwd_lds_kernel(GridParams
         }
     }
 }
+#endif  // LSE_DEV_KNOBS
 
 // Backward.  Lane mapping: 16 lanes per sample -- lane k of a 16-lane group owns (corner k>>1, feature k&1) -- and a
 // wave owns 64 consecutive samples of the packed (ray-sorted) stream, processed in 16 rounds of 4 samples.
@@ -477,6 +479,7 @@ __device__ __forceinline__ void seg_scan_cross_rows(float (&v)[16], int open, in
     for (int k = 0; k < 16; ++k) LSE_FMAC_DPP(v[k], fb, "row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
 
+#ifdef LSE_DEV_KNOBS   // development build only (csrc/dev_knobs.h): superseded / A-B variant, not in liblse_hip.so
 template <bool WITH_DX, int kSlots, int kEntLog2>
 __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
             }
     }
 }
+#endif  // LSE_DEV_KNOBS
 
 // kPair: the memory-side units charge a float-atomic REQUEST per 64-byte LINE, whatever part of it the request covers
 // (tools/micro/atomic_gran.hip: 21 G requests/s for 4 ... 64 contiguous bytes, half of that for 128).  With 32-byte slots a line
@@ -1262,6 +1266,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
 // workgroup and < 128 registers: the occupancy is set by the registers, and the waves of a SIMD hide each other's latencies.
 // Any level is handled correctly (a fine level just sends more requests than the cache would), so the split level is a
 // tuning parameter of the launch (lse_hash_bwd_opts.coarse_levels), not a correctness condition.
+#ifdef LSE_DEV_KNOBS   // development build only (csrc/dev_knobs.h): superseded / A-B variant, not in liblse_hip.so
 template <bool WITH_DX>
 __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
@@ -1377,6 +1382,7 @@ __global__ __launch_bounds__(256) void hash_bwd_coarse_kernel(GridParams g, cons
         dx[si * 3 + 2] = dacc2;
     }
 }
+#endif  // LSE_DEV_KNOBS
 
 // dtable[i] += sum over replicas; the workspace reads zero again afterwards (it is handed over zeroed and returned zeroed)
 __global__ __launch_bounds__(256) void hash_bwd_reduce_replicas_kernel(float *__restrict__ ws, float *__restrict__ dtable,
@@ -1427,7 +1433,7 @@ int fill_params(const lse_grid_desc *desc, GridParams &g, const char *who)
 }  // namespace
 
 extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const float *table, float *y, int64_t n,
-                            lse_stream_t stream)
+                            const int64_t *n_dev, lse_stream_t stream)
 {
     GridParams g;
     int rc = fill_params(desc, g, "lse_hash_fwd");
@@ -1437,37 +1443,35 @@ extern "C" int lse_hash_fwd(const lse_grid_desc *desc, const float *x01, const f
     LSE_REQUIRE(x01 && table && y, "lse_hash_fwd: null pointer");
     const int64_t chunks = (n + kFwdThreads * kFwdItems - 1) / (kFwdThreads * kFwdItems);
     const int mapping = (int)lse::option("hash_fwd_mapping");
-    // option hash_fwd_lds_levels = k: the k coarsest levels whose whole table fits one CU's LDS run in hash_fwd_lds_kernel (needs
-    // the default mapping 4, whose grid simply ends k levels earlier)
     int lds_levels = 0;
+    hipStream_t st = lse::as_stream(stream);
+#ifdef LSE_DEV_KNOBS
+    // knob hash_fwd_lds_levels = k: the k coarsest levels whose whole table fits one CU's LDS run in hash_fwd_lds_kernel (needs
+    // the default mapping 4, whose grid simply ends k levels earlier)
     if (mapping == 4) {
         const int want = (int)std::min<int64_t>(lse::option("hash_fwd_lds_levels"), g.n_levels - 1);
         while (lds_levels < want && (int64_t)(g.offsets[lds_levels + 1] - g.offsets[lds_levels]) * 8 <= 156 * 1024) ++lds_levels;
     }
-    hipStream_t st = lse::as_stream(stream);
     for (int l = 0; l < lds_levels; ++l) {
         const int lds_bytes = (int)(g.offsets[l + 1] - g.offsets[l]) * 8;
-        static int attr_bytes = 0;
-        if (lds_bytes > attr_bytes) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_fwd_lds_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e != hipSuccess) {
-                lse::set_error("lse_hash_fwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
-                return LSE_E_LAUNCH;
-            }
-            attr_bytes = lds_bytes;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hash_fwd_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);     // (per device: set per call)
+        if (e != hipSuccess) {
+            lse::set_error("lse_hash_fwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
+            return LSE_E_LAUNCH;
         }
         // as many workgroups as fit the chip at once with this much LDS each (16 waves per workgroup: at most 2 per CU)
         const int per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;
         const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(256 * per_cu, (n + 2 * kFwdLdsThreads - 1) / (2 * kFwdLdsThreads)));
         hipLaunchKernelGGL(hash_fwd_lds_kernel, dim3((unsigned)wgs), dim3(kFwdLdsThreads), lds_bytes, st, g, l, x01,
-                           reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, lse::device_count());
+                           reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, n_dev);
     }
+#endif
     const int64_t blocks = chunks * (g.n_levels - lds_levels);
     LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_fwd: grid too large");
     hipLaunchKernelGGL(hash_fwd_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, st, g, x01,
                        reinterpret_cast<const float2 *>(table), reinterpret_cast<float2 *>(y), n, chunks, mapping,
-                       lse::device_count(), lds_levels);
+                       n_dev, lds_levels);
     return lse::check_launch("lse_hash_fwd");
 }
 
@@ -1523,25 +1527,35 @@ extern "C" int64_t lse_hash_bwd_workspace_bytes(const lse_grid_desc *desc, const
 }
 
 extern "C" int lse_hash_bwd(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
-                            float *dtable, float *dx, int64_t n, lse_stream_t stream)
+                            float *dtable, float *dx, int64_t n, const int64_t *n_dev, lse_stream_t stream)
 {
-    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, 0, 0, desc ? desc->n_levels : 0, n, nullptr, stream);
+    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, 0, 0, desc ? desc->n_levels : 0, n, n_dev, nullptr, stream);
 }
 
 extern "C" int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                                    float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin,
-                                   int32_t level_end, int64_t n, lse_stream_t stream)
+                                   int32_t level_end, int64_t n, const int64_t *n_dev, lse_stream_t stream)
 {
-    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, dx_accumulate, level_begin, level_end, n, nullptr, stream);
+    return lse_hash_bwd_ex(desc, x01, dy, table, dtable, dx, dx_accumulate, level_begin, level_end, n, n_dev, nullptr, stream);
 }
 
 extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, const float *dy, const float *table,
                                float *dtable, float *dx, int32_t dx_accumulate, int32_t level_begin, int32_t level_end,
-                               int64_t n, const lse_hash_bwd_opts *opts, lse_stream_t stream)
+                               int64_t n, const int64_t *n_dev, const lse_hash_bwd_opts *opts, lse_stream_t stream)
 {
     lse_hash_bwd_opts o;
     lse_hash_bwd_default_opts(&o);
     if (opts) o = *opts;
+#ifndef LSE_DEV_KNOBS
+    // the library that ships holds the production variants only: the batched sector-cache kernel (impl 2, gran 6) and the generic
+    // 16-lanes-per-sample kernel (impl 0; also taken for grids whose levels do not start on 64-byte lines)
+    if (!((o.impl == 2 && o.gran == 6 && !o.prefetch) || o.impl == 0) || o.coarse_levels != 0 || o.dbg != 0 || o.rounds != 32 ||
+        o.interleave_from_scale < 1e29f) {
+        lse::set_error("lse_hash_bwd: impl %d / gran %d / prefetch %d / coarse_levels %d / rounds %d / dbg %d selects a development "
+                       "variant (csrc/dev_knobs.h: build liblse_hip_dev.so)", o.impl, o.gran, o.prefetch, o.coarse_levels, o.rounds, o.dbg);
+        return LSE_E_UNSUPPORTED;
+    }
+#endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
     LSE_REQUIRE(o.gran >= 2 && o.gran <= 7, "lse_hash_bwd: opts.gran must be 2 .. 7");
@@ -1563,10 +1577,10 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     LSE_REQUIRE(o.coarse_levels >= 0 && o.coarse_levels <= LSE_MAX_GRID_LEVELS, "lse_hash_bwd: opts.coarse_levels out of range");
     const float il_scale = o.interleave_from_scale;
     const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
+    (void)rounds;
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
-    // device-side sample count (lse_set_device_count): honoured by the default kernel and the coarse kernel
-    const int64_t *n_dev = lse::device_count();
+    // device-side sample count: honoured by the default kernel (and the development build's coarse kernel)
     LSE_REQUIRE(!n_dev || (impl == 2), "lse_hash_bwd: a device-side count needs opts.impl == 2");
     // replicas of the coarsest levels for the direct adds (impl 2's few-runs path and the coarse kernel)
     float *ws = nullptr;
@@ -1592,6 +1606,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
                                (uint32_t)floats);
         }
     } reduce_at_exit{ws, dtable, rep_floats, o.replicas, st};
+#ifdef LSE_DEV_KNOBS
     // the coarse share of the level range first, in the cache-free kernel; the rest of the range then accumulates into dx
     const int coarse_end = std::min<int>(o.coarse_levels, level_end);
     if (coarse_end > level_begin) {
@@ -1611,6 +1626,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         g.l_begin = coarse_end;
         g.dx_accumulate = 1;
     }
+#endif
     // line-cache kernel: needs every level to start on a 64-B line (tcnn pads level sizes to 8 entries)
     bool lines_ok = true;
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
@@ -1620,6 +1636,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+#ifdef LSE_DEV_KNOBS
         if (o.gran == 5) {      // the same with 256 slots: half the LDS, three workgroups per CU
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
@@ -1641,6 +1658,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
+#endif
         if (o.gran == 6) {      // gran 4 with the second-generation flush (fewer DS instructions per cache pass)
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
@@ -1648,6 +1666,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
+#ifdef LSE_DEV_KNOBS
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
@@ -1660,7 +1679,12 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                 tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
         return lse::check_launch("lse_hash_bwd");
+#else
+        lse::set_error("lse_hash_bwd: opts.gran %d is a development variant", o.gran);     // (rejected above already)
+        return LSE_E_UNSUPPORTED;
+#endif
     }
+#ifdef LSE_DEV_KNOBS
     if (impl >= 1 && lines_ok) {
         const int few_runs = o.few_runs, second_probe = o.second_probe, gran = o.gran;
         const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
@@ -1680,6 +1704,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #undef LSE_LAUNCH_CACHED
         return lse::check_launch("lse_hash_bwd");
     }
+#endif
 #define LSE_LAUNCH_BWD(R)                                                                                             \
     do {                                                                                                              \
         const int64_t blocks = (n + 4 * 4 * R - 1) / (4 * 4 * R);                                                     \
@@ -1689,9 +1714,12 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         else hipLaunchKernelGGL((hash_bwd_kernel<false, R>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy, tb,   \
                                 dtable, dx, n, il_scale, dbg);                                                        \
     } while (0)
-    if (rounds == 32) LSE_LAUNCH_BWD(32);
-    else if (rounds == 64) LSE_LAUNCH_BWD(64);
-    else LSE_LAUNCH_BWD(16);
+#ifdef LSE_DEV_KNOBS
+    if (rounds == 64) LSE_LAUNCH_BWD(64);
+    else if (rounds == 16) LSE_LAUNCH_BWD(16);
+    else
+#endif
+    LSE_LAUNCH_BWD(32);
 #undef LSE_LAUNCH_BWD
     return lse::check_launch("lse_hash_bwd");
 }

@@ -42,7 +42,7 @@ struct MlpArgs {
     float *out;
     float *act;
     int64_t n;                   // samples (a capacity when n_dev is set: every kernel clamps it first)
-    const int64_t *n_dev;        // lse_set_device_count
+    const int64_t *n_dev;        // device-side sample count (nullable)
     int64_t n_stride;            // the host-side n: level stride of level-major inputs / gradients, layer stride of row-major activations
     int out_activation;
     // backward
@@ -66,6 +66,7 @@ struct MlpArgs {
     // Lets the head consume the density logit + 15 geometry features h[N,16] against columns 15..30 of tcnn's [W x 64]
     // input matrix in place -- no split / concatenated copy of the parameters per step.
     int w0_ld, w0_col, w0_mask0;
+    int arith;                   // lse_mlp_desc.arith (host-side dispatch only)
     int64_t rest_off;
 };
 
@@ -1389,6 +1390,7 @@ int check_desc(const lse_mlp_desc *d, const char *who)
     LSE_REQUIRE(d->w0_ld == 0 || d->w0_ld >= d->w0_col + d->n_in, "%s: first-layer view [%d, %d) exceeds its leading dimension %d",
                 who, d->w0_col, d->w0_col + d->n_in, d->w0_ld);
     LSE_REQUIRE(d->w0_col >= 0 && (d->w0_ld != 0 || d->w0_col == 0), "%s: w0_col needs w0_ld", who);
+    LSE_REQUIRE(d->arith == LSE_MLP_ARITH_AUTO || d->arith == LSE_MLP_ARITH_F32_MFMA, "%s: bad arith", who);
     return LSE_OK;
 }
 
@@ -1397,6 +1399,7 @@ void fill_view(MlpArgs &a, const lse_mlp_desc *d)
     a.w0_ld = d->w0_ld ? d->w0_ld : d->n_in;
     a.w0_col = d->w0_col;
     a.w0_mask0 = d->w0_mask_col0;
+    a.arith = d->arith;
     a.rest_off = (int64_t)d->width * a.w0_ld;
 }
 
@@ -1417,7 +1420,7 @@ int launch_fwd(const MlpArgs &a, hipStream_t st)
     const int cfg = (int)lse::option("mlp_fwd_cfg");   // CT*10 + NW
     if constexpr (WIDTH == 64 && ((KIN == 16 && INL == LSE_IN_ROWMAJOR) || KIN == 32)) {
         // third generation: f32-equivalent arithmetic on the bf16 matrix cores (mlp_x6.h)
-        if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") == 2) {
+        if (cfg == 28 && (a.act == nullptr || a.act_tiled) && a.arith == LSE_MLP_ARITH_AUTO) {
             const int64_t tiles3 = (a.n + 31) / 32;
             const int blocks3 = (int)std::min<int64_t>((tiles3 + 7) / 8, 512);
             constexpr int lds3 = X6Fwd<KIN, NHL, INL>::lds_bytes;
@@ -1426,7 +1429,7 @@ int launch_fwd(const MlpArgs &a, hipStream_t st)
             return lse::check_launch("lse_mlp_fwd");
         }
     }
-    if (cfg == 28 && (a.act == nullptr || a.act_tiled) && lse::option("mlp_fwd_impl") >= 1) {
+    if (cfg == 28 && (a.act == nullptr || a.act_tiled)) {
         constexpr int HB2 = WIDTH / 16;
         constexpr int imgs2 = HB2 * (KIN / 4) + (NHL == 2 ? HB2 * (WIDTH / 4) : 0) + WIDTH / 4;
         const int64_t tiles2 = (a.n + 31) / 32;
@@ -1439,10 +1442,10 @@ int launch_fwd(const MlpArgs &a, hipStream_t st)
         lse::set_error("lse_mlp_fwd: act_tiled = 2 is only understood by the second-generation fused forward");
         return LSE_E_UNSUPPORTED;
     }
-    switch (cfg) {      // (216 / 116 / 24 were measured and dropped in round 1: DESIGN.md section 4.1)
-    case 44: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
-    default: return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
-    }
+#ifdef LSE_DEV_KNOBS
+    if (cfg == 44) return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);     // (216 / 116 / 24 were measured and dropped in round 1)
+#endif
+    return launch_fwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);      // row-major saved activations (what lse_mlp_wgrad reads)
 }
 
 template <int KIN, int WIDTH, int NHL, int INL, int CT, int NW>
@@ -1522,12 +1525,15 @@ int launch_bwd3_cfg(const MlpArgs &a, hipStream_t st)
 template <int KIN, int NHL, int INL, bool BIAS, bool BIAS_ONES>
 int launch_bwd3(const MlpArgs &a, hipStream_t st)
 {
+#ifdef LSE_DEV_KNOBS
     switch ((int)lse::option("mlp_bwd3_cfg")) {      // CT * 100 + NW
     case 112: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 12>(a, st);
     case 108: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 1, 8>(a, st);
     case 204: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 4>(a, st);      // one wave per SIMD, 512 registers, free scheduling
-    default: return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 8>(a, st);
+    default: break;
     }
+#endif
+    return launch_bwd3_cfg<KIN, NHL, INL, BIAS, BIAS_ONES, 2, 8>(a, st);
 }
 
 template <int KIN, int WIDTH, int NHL, int INL>
@@ -1565,10 +1571,11 @@ int launch_bwd(const MlpArgs &a, hipStream_t st)
         lse::set_error("lse_mlp_bwd: act_tiled = 2 is only understood by the second-generation fused backward");
         return LSE_E_UNSUPPORTED;
     }
-    switch (cfg) {
-    case 44: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
-    default: return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
-    }
+#ifdef LSE_DEV_KNOBS
+    if (cfg == 44) return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 4, 4>(a, st);
+#endif
+    // the generic kernel: data gradients alone (frozen parameters), materialised activation gradients, row-major activations
+    return launch_bwd_cfg<KIN, WIDTH, NHL, INL, 2, 8>(a, st);
 }
 
 #define LSE_MLP_DISPATCH(FN, d, a, st)                                                                   \
@@ -1636,7 +1643,8 @@ int gemm_tn_dispatch(const float *g, int m, const float *a, int k, int al, int64
 
 extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const float *in, const float *row_bias,
                            const int32_t *row_bias_idx, float *out, int32_t out_cols, float *act, int32_t act_tiled,
-                           float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, lse_stream_t stream)
+                           float *sigma_out, const uint8_t *selector, float density_scale, int64_t n, const int64_t *n_dev,
+                           lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_fwd");
     if (rc) return rc;
@@ -1646,7 +1654,7 @@ extern "C" int lse_mlp_fwd(const lse_mlp_desc *desc, const float *params, const 
     MlpArgs a{};
     LSE_REQUIRE(out_cols == 16 || out_cols == 4, "lse_mlp_fwd: out_cols must be 16 or 4");
     a.params = params; a.in = in; a.row_bias = row_bias; a.row_bias_idx = row_bias_idx; a.out = out; a.act = act;
-    a.n = n; a.n_stride = n; a.n_dev = lse::device_count();
+    a.n = n; a.n_stride = n; a.n_dev = n_dev;
     a.out_activation = desc->out_activation; a.out_cols = out_cols; a.sigma_out = sigma_out;
     a.selector = selector; a.density_scale = density_scale;
     a.act_tiled = act_tiled;
@@ -1660,7 +1668,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
                            int32_t act_tiled, const float *out, int32_t out_cols, const float *d_out, const float *d_sigma,
                            const uint8_t *selector, float density_scale, float *d_out_pre, float *d_act, float *d_act0,
                            float *d_in, float *d_params, const float *row_bias, const int32_t *row_bias_idx,
-                           float *d_row_bias, int64_t n, lse_stream_t stream)
+                           float *d_row_bias, int64_t n, const int64_t *n_dev, lse_stream_t stream)
 {
     int rc = check_desc(desc, "lse_mlp_bwd");
     if (rc) return rc;
@@ -1677,7 +1685,7 @@ extern "C" int lse_mlp_bwd(const lse_mlp_desc *desc, const float *params, const 
     MlpArgs a{};
     a.params = params; a.in = in; a.act = const_cast<float *>(act); a.out = const_cast<float *>(out); a.d_out = d_out;
     a.d_out_pre = d_out_pre; a.d_act = d_act; a.d_act0 = d_act0; a.d_in = d_in; a.d_params = d_params; a.n = n;
-    a.n_stride = n; a.n_dev = lse::device_count();
+    a.n_stride = n; a.n_dev = n_dev;
     a.out_activation = desc->out_activation; a.out_cols = out_cols; a.d_sigma = d_sigma; a.selector = selector;
     a.density_scale = density_scale;
     a.act_tiled = act_tiled;
@@ -1704,7 +1712,6 @@ extern "C" int lse_mlp_wgrad(const lse_mlp_desc *desc, const float *in, const fl
     int rc = check_desc(desc, "lse_mlp_wgrad");
     if (rc) return rc;
     LSE_REQUIRE(n >= 0, "lse_mlp_wgrad: n < 0");
-    LSE_REQUIRE(!lse::device_count(), "lse_mlp_wgrad does not take a device-side count (lse_set_device_count)");
     if (n == 0) return LSE_OK;
     LSE_REQUIRE(in && act && d_act && d_out_pre && d_params, "lse_mlp_wgrad: null pointer");
     LSE_REQUIRE((desc->w0_ld == 0 || desc->w0_ld == desc->n_in) && !desc->w0_mask_col0,

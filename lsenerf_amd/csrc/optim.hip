@@ -12,10 +12,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    float b1, float b2, float eps, float bc1, float inv_sqrt_bc2,
                                                    float gscale, const float *__restrict__ hyper)
 {
-    if (hyper != nullptr) {      // step-dependent scalars from device memory (a captured launch cannot carry new ones)
+    if (hyper != nullptr) {      // every scalar of the step from device memory (a captured launch cannot carry new ones)
         lr = hyper[0];
         bc1 = hyper[1];
         inv_sqrt_bc2 = hyper[2];
+        b1 = hyper[3];
+        b2 = hyper[4];
+        eps = hyper[5];
     }
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -52,10 +55,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 // One thread: advance the device-side step counter and derive the step's scalars from it, in double like the host does for
 // lse_adam_step.  Captured into a HIP graph in front of adam_kernel, a replayed step needs nothing from the host: there is no
 // staging buffer a host that runs ahead of the device could overwrite before the queued copy has executed.
-__global__ void adam_schedule_kernel(int64_t *__restrict__ step, float *__restrict__ hyper, double lr_init, double lr_final,
-                                     int64_t max_steps, double b1, double b2)
+__global__ void adam_schedule_kernel(int64_t *__restrict__ step, float *__restrict__ hyper, const double *__restrict__ sched)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the schedule's constants live in device memory too: a host that changes them (a loaded param group, a manual lr drop)
+    // rewrites six doubles and every later replay follows
+    const double lr_init = sched[0], lr_final = sched[1], b1 = sched[3], b2 = sched[4];
+    const int64_t max_steps = (int64_t)sched[2];
     const int64_t done = *step;                 // optimizer steps taken so far: the learning rate is the one of step `done`
     const int64_t t = done + 1;
     *step = t;
@@ -67,6 +73,9 @@ __global__ void adam_schedule_kernel(int64_t *__restrict__ step, float *__restri
     hyper[0] = (float)lr;
     hyper[1] = (float)(1.0 - pow(b1, (double)t));
     hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, (double)t)));
+    hyper[3] = (float)b1;
+    hyper[4] = (float)b2;
+    hyper[5] = (float)sched[5];
 }
 
 // occs[id] = max(occs[id]*ema, occ_new) with duplicate ids resolved as the maximum over the duplicates:
@@ -119,7 +128,7 @@ extern "C" int lse_adam_step(float *params, const float *grads, float *exp_avg, 
 }
 
 extern "C" int lse_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
-                                 const float *hyper, float beta1, float beta2, float eps, float grad_scale, lse_stream_t stream)
+                                 const float *hyper, float grad_scale, lse_stream_t stream)
 {
     LSE_REQUIRE(n >= 0, "lse_adam_step_dev: n < 0");
     if (n == 0) return LSE_OK;
@@ -129,18 +138,14 @@ extern "C" int lse_adam_step_dev(float *params, const float *grads, float *exp_a
     const int64_t n4 = (n + 3) / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 2048));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, lse::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
-                       n, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, hyper);
+                       n, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, hyper);
     return lse::check_launch("lse_adam_step_dev");
 }
 
-extern "C" int lse_adam_schedule_dev(int64_t *step, float *hyper, double lr_init, double lr_final, int64_t max_steps,
-                                     double beta1, double beta2, lse_stream_t stream)
+extern "C" int lse_adam_schedule_dev(int64_t *step, float *hyper, const double *sched, lse_stream_t stream)
 {
-    LSE_REQUIRE(step && hyper, "lse_adam_schedule_dev: null pointer");
-    LSE_REQUIRE(lr_init > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0,
-                "lse_adam_schedule_dev: need lr_init > 0 and betas in [0, 1)");
-    hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(64), 0, lse::as_stream(stream), step, hyper, lr_init, lr_final,
-                       max_steps, beta1, beta2);
+    LSE_REQUIRE(step && hyper && sched, "lse_adam_schedule_dev: null pointer");
+    hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(64), 0, lse::as_stream(stream), step, hyper, sched);
     return lse::check_launch("lse_adam_schedule_dev");
 }
 

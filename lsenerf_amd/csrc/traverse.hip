@@ -36,7 +36,7 @@ struct TraverseArgs {
     int64_t cap;          // MODE 2: samples of ray r go to slots [r*cap, (r+1)*cap)
     int32_t *overflow;    // MODE 2: OR-ed (never cleared) when a ray produced more than cap samples (never, by the host's bound)
     int vec_march;        // constant step: march 64 steps of a cell at once (march_cell_vec); 0 = published serial loop only
-    int fma_setup;        // option "traverse_fma": the a*b+c sites of the traversal setup as fused multiply-adds (nvcc's default
+    int fma_setup;        // flags & LSE_TRAVERSE_FMA_SETUP: the a*b+c sites of the traversal setup as fused multiply-adds (nvcc's default
                           // contraction of grid.cu); 0 = every product and sum rounded separately (default, == oracle build 1)
 };
 
@@ -498,7 +498,7 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
                                   const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
                                   const float *near_planes, const float *far_planes, float step_size,
                                   float cone_angle, int32_t mode, int64_t *chunk_cnts, const int64_t *chunk_starts,
-                                  int32_t *ray_indices, float *t_starts, float *t_ends, lse_stream_t stream)
+                                  int32_t *ray_indices, float *t_starts, float *t_ends, int32_t flags, lse_stream_t stream)
 {
     LSE_REQUIRE(n_rays >= 0, "lse_traverse_grids: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
@@ -511,7 +511,7 @@ extern "C" int lse_traverse_grids(const float *rays_o, const float *rays_d, int3
     if (mode == 0) LSE_REQUIRE(chunk_cnts, "lse_traverse_grids: count pass needs chunk_cnts");
     if (mode == 1) LSE_REQUIRE(chunk_starts && ray_indices && t_starts && t_ends, "lse_traverse_grids: write pass needs outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr, vec_march_enabled(), (int)lse::option("traverse_fma")};
+                   step_size, cone_angle, chunk_cnts, chunk_starts, ray_indices, t_starts, t_ends, 0, nullptr, vec_march_enabled(), (flags & LSE_TRAVERSE_FMA_SETUP) ? 1 : 0};
     const int blocks = n_rays;   // one wave per ray
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
@@ -529,7 +529,7 @@ extern "C" int lse_traverse_grids_slots(const float *rays_o, const float *rays_d
                                         const float *aabbs, int32_t levels, int32_t rx, int32_t ry, int32_t rz,
                                         const float *near_planes, const float *far_planes, float step_size,
                                         float cone_angle, int64_t cap, int64_t *chunk_cnts, float *t_start_slots,
-                                        float *t_end_slots, int32_t *overflow, lse_stream_t stream)
+                                        float *t_end_slots, int32_t *overflow, int32_t flags, lse_stream_t stream)
 {
     LSE_REQUIRE(n_rays >= 0, "lse_traverse_grids_slots: n_rays < 0");
     if (n_rays == 0) return LSE_OK;
@@ -540,7 +540,7 @@ extern "C" int lse_traverse_grids_slots(const float *rays_o, const float *rays_d
     LSE_REQUIRE((int64_t)levels * rx * ry * rz < (1ll << 31), "lse_traverse_grids_slots: grid too large (levels*cells >= 2^31)");
     LSE_REQUIRE(cap >= 1 && chunk_cnts && t_start_slots && t_end_slots && overflow, "lse_traverse_grids_slots: bad outputs");
     TraverseArgs a{rays_o, rays_d, n_rays, binaries, aabbs, levels, rx, ry, rz, near_planes, far_planes,
-                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow, vec_march_enabled(), (int)lse::option("traverse_fma")};
+                   step_size, cone_angle, chunk_cnts, nullptr, nullptr, t_start_slots, t_end_slots, cap, overflow, vec_march_enabled(), (flags & LSE_TRAVERSE_FMA_SETUP) ? 1 : 0};
     const bool const_dt = cone_angle == 0.0f && step_size > 0.0f && step_size <= 1e10f;
     hipStream_t st = lse::as_stream(stream);
     if (const_dt) hipLaunchKernelGGL((traverse_kernel<2, true>), dim3(n_rays), dim3(64), 0, st, a);

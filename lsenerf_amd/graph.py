@@ -4,7 +4,7 @@ In the configuration LSENeRF trains in (3510 rays per step, ~260 samples per ray
 2.8 ms, but issuing them from Python -- ~26 C-ABI launches, a dozen autograd nodes each way, ~40 allocations -- takes 3.3 ms
 of host time, and the two read-backs of the sampler's sample counts stop the host from running ahead of the GPU
 (bench.py ``cfg2_composition``: 3.6 - 4.5 ms per step depending on the box's CPU).  The reference pays the same kind of cost
-in nerfstudio's trainer.  With the counts kept on the device (``LSENeRFModel.deferred_counts``, lse_set_device_count) nothing in
+in nerfstudio's trainer.  With the counts kept on the device (``LSENeRFModel.deferred_counts``, the ``n_dev`` argument of the per-sample entry points) nothing in
 a step depends on the host any more, so the step -- sampler, visibility pre-pass, field, volume rendering, loss epilogue,
 backward, Adam -- is captured once into a HIP graph (``torch.cuda.graph``: the C-ABI launches go to torch's current stream,
 which is the capturing stream) and replayed with one call per step.

@@ -69,6 +69,10 @@ class LSEOccGridEstimator(nn.Module):
         self._occ_mean_host: Optional[float] = None   # cached occs.mean() (refreshed by _update), saves a sync per forward
         self.update_seed: int = 0x15E5EED             # base of the rank-independent update stream (same on every rank)
         self.after_march_hook: Optional[Callable[[], None]] = None   # dist.GradPipeline.flush: runs before sigma_fn
+        # arithmetic convention of the traversal set-up (include/lse_hip.h: LSE_TRAVERSE_FMA_SETUP): False = every product and sum
+        # rounded separately (bit-exact against oracle/c/liblse_oracle.so); True = nvcc's default contraction of nerfacc's grid.cu
+        # (bit-exact against liblse_oracle_fma.so).  About one sample interval per million differs.
+        self.traverse_fma: bool = False
 
     # ---------------------------------------------------------------------------------------------
     def _binaries_u8(self) -> Tensor:
@@ -184,7 +188,7 @@ class LSEOccGridEstimator(nn.Module):
                                                  render_step_size)
         ray_indices, t_starts, t_ends, packed_info = ops.traverse_grids(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
-            render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane))
+            render_step_size, cone_angle, max_span=self._max_span(near_plane, far_plane), fma_setup=self.traverse_fma)
 
         if self.after_march_hook is not None:   # e.g. finish the previous step's all-reduce + Adam (dist.GradPipeline)
             self.after_march_hook()
@@ -242,7 +246,8 @@ class LSEOccGridEstimator(nn.Module):
         cap = self._cap_per_ray(near_plane, far_plane, render_step_size, cone_angle)
         res = ops.traverse_grids_deferred(
             rays_o.contiguous(), rays_d.contiguous(), self._binaries_u8(), self.aabbs, near_planes, far_planes,
-            render_step_size, cone_angle, cap, out=None if out is None else tuple(out)[:6], overflow=self._overflow_flag())
+            render_step_size, cone_angle, cap, out=None if out is None else tuple(out)[:6], overflow=self._overflow_flag(),
+            fma_setup=self.traverse_fma)
         return Premarched(*res, self.grid_version, rays_o.shape[0])
 
     def _sampling_deferred(self, rays_o, rays_d, sigma_fn, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,

@@ -459,7 +459,7 @@ class LSENeRFModel(nn.Module):
         return metrics
 
     def correct_evs_dim(self, inp):
-        return self.rgb_to_one(inp) if self.config.ev_one_dim else inp
+        return self._run_module(self.rgb_to_one, inp) if self.config.ev_one_dim else inp
 
     def use_deferred_counts(self, num_rays: int) -> bool:
         """Whether a batch of ``num_rays`` rays takes the count-free sampler path (``deferred_counts`` and the slot budget)."""
@@ -570,7 +570,7 @@ class LSENeRFModel(nn.Module):
         routed = dict(out_dict)
         rgb_mapper = lambda *a, **k: self._run_module(self.rgb_mapper, *a, **k)
         evs_mapper = lambda *a, **k: self._run_module(self.evs_mapper, *a, **k)
-        correct_evs_dim = lambda *a, **k: self._run_module(self.correct_evs_dim, *a, **k)
+        correct_evs_dim = self.correct_evs_dim
         if plan["mode"] == "rgb_evs":
             if events_wanted:
                 routed["ev_out"] = rgb_mapper(correct_evs_dim(linear))

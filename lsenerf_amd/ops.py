@@ -46,18 +46,19 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_N_DEV_AT = {"lse_positions_fwd": 6, "lse_positions_bwd": 6, "lse_hash_bwd_ex": 10}     # elsewhere: right before the stream
+
+
 def _call_n(name: str, n_dev: Optional[torch.Tensor], *args):
-    """``_lib.call`` of a per-sample entry point with a device-side sample count (lse_set_device_count): the ``n`` among
-    ``args`` is then a CAPACITY and the kernels clamp it to ``n_dev[0]`` (int64, on the device).  ``n_dev is None``: plain call."""
-    if n_dev is None:
-        return _lib.call(name, *args)
-    assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() >= 1
-    lib = _lib.load()
-    lib.lse_set_device_count(ctypes.c_void_p(n_dev.data_ptr()))
-    try:
-        _lib.call(name, *args)
-    finally:
-        lib.lse_set_device_count(None)
+    """``_lib.call`` of a per-sample entry point: inserts the ``n_dev`` argument (include/lse_hip.h: device-side sample count,
+    right behind ``n``).  With a tensor (int64, on the device) the ``n`` among ``args`` is a CAPACITY and the kernels clamp it to
+    ``n_dev[0]``; ``None``: plain call."""
+    ptr = None
+    if n_dev is not None:
+        assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() >= 1
+        ptr = ctypes.c_void_p(n_dev.data_ptr())
+    at = _N_DEV_AT.get(name, len(args) - 1)
+    return _lib.call(name, *args[:at], ptr, *args[at:])
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -124,6 +125,7 @@ class MlpMeta:
     w0_ld: int = 0            # first-layer view into params (include/lse_hip.h: lse_mlp_desc); 0 = plain layout
     w0_col: int = 0
     w0_mask_col0: int = 0
+    arith: int = _lib.LSE_MLP_ARITH_AUTO      # forward arithmetic route where two are built (include/lse_hip.h: lse_mlp_desc.arith)
 
     @property
     def n_params(self):
@@ -131,7 +133,7 @@ class MlpMeta:
 
     def desc(self) -> MlpDesc:
         return MlpDesc(self.n_in, self.width, self.n_hidden_layers, self.out_activation, self.in_layout, self.w0_ld,
-                       self.w0_col, self.w0_mask_col0)
+                       self.w0_col, self.w0_mask_col0, self.arith)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -143,14 +145,16 @@ SYNC_STATS = {"seconds": 0.0, "count": 0}   # host time spent blocked in the sam
 
 @torch.no_grad()
 def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
-                   max_span: float = None):
+                   max_span: float = None, fma_setup: bool = False):
     """nerfacc.grid.traverse_grids as consumed at R:lse_nerf/lse_grid_estimator.py:93-106.
     Returns (ray_indices int32 [N], t_starts [N], t_ends [N], packed_info int64 [R,2]).  One host sync (N).
 
     max_span: host-known upper bound of (t_exit - t_enter) over all rays (clipped by the planes and the outermost aabb).
     With it the march runs ONCE into fixed-capacity per-ray slots (every sample interval is >= step_size long, so
     cap = max_span / step_size + slack bounds the count) and a copy kernel packs them; without it (or when the slots
-    would be too large) the published count pass + write pass run."""
+    would be too large) the published count pass + write pass run.
+    fma_setup: LSE_TRAVERSE_FMA_SETUP -- nvcc's default contraction at the four a*b+c sites of the traversal set-up."""
+    flags = _lib.LSE_TRAVERSE_FMA_SETUP if fma_setup else 0
     R = rays_o.shape[0]
     L, rx, ry, rz = binaries.shape
     dev = rays_o.device
@@ -168,7 +172,7 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
             flag = total[1:].view(torch.int32)    # low word of total[1]
             _lib.call("lse_traverse_grids_slots", *args, cap, ctypes.c_void_p(cnts.data_ptr()),
                       ctypes.c_void_p(ts_slots.data_ptr()), ctypes.c_void_p(te_slots.data_ptr()),
-                      ctypes.c_void_p(flag.data_ptr()), _stream())
+                      ctypes.c_void_p(flag.data_ptr()), flags, _stream())
             _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
                       ctypes.c_void_p(total.data_ptr()), _stream())
             _t0 = time.perf_counter()
@@ -185,7 +189,7 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
                               ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(te.data_ptr()), _stream())
                 return ri, ts, te, packed
             total.zero_()   # bound violated (not expected): redo with the two-pass scheme
-    _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, _stream())
+    _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, flags, _stream())
     _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
     n = int(total[0].item())
@@ -196,13 +200,13 @@ def traverse_grids(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, ste
         starts = packed[:, 0].contiguous()
         _lib.call("lse_traverse_grids", *args, 1, None, ctypes.c_void_p(starts.data_ptr()),
                   ctypes.c_void_p(ri.data_ptr()), ctypes.c_void_p(ts.data_ptr()), ctypes.c_void_p(te.data_ptr()),
-                  _stream())
+                  flags, _stream())
     return ri, ts, te, packed
 
 
 @torch.no_grad()
 def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size: float, cone_angle: float,
-                            cap: int, out=None, overflow=None):
+                            cap: int, out=None, overflow=None, fma_setup: bool = False):
     """``traverse_grids`` without the host read-back of the sample count.  ``cap`` is a PROVEN upper bound of the samples of
     one ray (LSEOccGridEstimator._cap_per_ray); the packed outputs have room for ``R * cap`` samples and the actual count stays
     on the device.  Returns (ray_indices int32 [C], t_starts [C], t_ends [C], packed_info int64 [R,2], n_dev int64 [1],
@@ -238,7 +242,7 @@ def traverse_grids_deferred(rays_o, rays_d, binaries, aabbs, near_planes, far_pl
     _lib.call("lse_traverse_grids_slots", _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), R, _chk(binaries, torch.uint8, "binaries"),
               _f32(aabbs, "aabbs"), L, rx, ry, rz, _f32(near_planes, "near_planes"), _f32(far_planes, "far_planes"),
               float(step_size), float(cone_angle), cap, ctypes.c_void_p(cnts.data_ptr()), ctypes.c_void_p(ts_slots.data_ptr()),
-              ctypes.c_void_p(te_slots.data_ptr()), flag, _stream())
+              ctypes.c_void_p(te_slots.data_ptr()), flag, _lib.LSE_TRAVERSE_FMA_SETUP if fma_setup else 0, _stream())
     _lib.call("lse_pack_info_from_counts", ctypes.c_void_p(cnts.data_ptr()), R, ctypes.c_void_p(packed.data_ptr()),
               ctypes.c_void_p(total.data_ptr()), _stream())
     if out is None:
@@ -624,7 +628,7 @@ class _MlpFn(torch.autograd.Function):
             _lib.call("lse_mlp_bwd", ctypes.byref(desc), _f32(params, "params"), _f32(x, "mlp input"), _f32(act, "act"),
                       0, _f32(out, "out"), out_cols, _f32(d_out, "d_out"), _f32(d_sigma, "d_sigma", True), sel, scale,
                       ctypes.c_void_p(d_out_pre.data_ptr()), ctypes.c_void_p(d_act.data_ptr()), None,
-                      _f32(d_in, "d_in", True), None, None, None, None, n, _stream())
+                      _f32(d_in, "d_in", True), None, None, None, None, n, None, _stream())
             _lib.call("lse_mlp_wgrad", ctypes.byref(desc), _f32(x, "mlp input"), _f32(act, "act"),
                       ctypes.c_void_p(d_act.data_ptr()), ctypes.c_void_p(d_out_pre.data_ptr()),
                       ctypes.c_void_p(d_params.data_ptr()), n, _stream())
@@ -1118,19 +1122,20 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step: i
 
 
 @torch.no_grad()
-def adam_step_dev(params, grads, exp_avg, exp_avg_sq, hyper, beta1, beta2, eps, grad_scale: float = 1.0):
-    """Adam with the step-dependent scalars (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) in ``hyper`` (float32 [3] on the device)."""
+def adam_step_dev(params, grads, exp_avg, exp_avg_sq, hyper, grad_scale: float = 1.0):
+    """Adam with every scalar of the step -- lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t), beta1, beta2, eps -- in ``hyper`` (float32 [6]
+    on the device, written by ``adam_schedule_dev``)."""
     _lib.call("lse_adam_step_dev", _f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"),
-              _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), _f32(hyper, "hyper"), float(beta1), float(beta2), float(eps),
-              float(grad_scale), _stream())
+              _f32(exp_avg_sq, "exp_avg_sq"), params.numel(), _f32(hyper, "hyper"), float(grad_scale), _stream())
 
 
 @torch.no_grad()
-def adam_schedule_dev(step_dev, hyper, lr_init: float, lr_final: Optional[float], max_steps: Optional[int], beta1, beta2):
-    """Advance the device-side optimizer step counter (int64 [1]) and write (lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)) of the new
-    step into ``hyper`` (float32 [3]) -- lse_adam_schedule_dev; capturable, reads nothing from the host."""
-    _lib.call("lse_adam_schedule_dev", _chk(step_dev, torch.int64, "step_dev"), _f32(hyper, "hyper"), float(lr_init),
-              float(lr_final) if lr_final else 0.0, int(max_steps) if max_steps else 0, float(beta1), float(beta2), _stream())
+def adam_schedule_dev(step_dev, hyper, sched):
+    """Advance the device-side optimizer step counter (int64 [1]) and write the six scalars of the new step into ``hyper``
+    (float32 [6]) from the schedule constants ``sched`` (float64 [6] on the device: lr_init, lr_final, max_steps, beta1, beta2,
+    eps) -- lse_adam_schedule_dev; capturable, reads nothing from the host."""
+    _lib.call("lse_adam_schedule_dev", _chk(step_dev, torch.int64, "step_dev"), _f32(hyper, "hyper"),
+              _chk(sched, torch.float64, "sched"), _stream())
 
 
 @torch.no_grad()

@@ -84,28 +84,43 @@ class FlatAdam:
     def _device_clock(self):
         if not hasattr(self, "_hyper_dev"):
             dev = self.flat.data.device
-            self._hyper_dev = torch.zeros(3, dtype=torch.float32, device=dev)
+            self._hyper_dev = torch.zeros(6, dtype=torch.float32, device=dev)
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._sched_dev = torch.zeros(6, dtype=torch.float64, device=dev)
             self._step_dev_expected = None
+            self._sched_uploaded = None
         return self._step_dev, self._hyper_dev
+
+    def _schedule_constants(self):
+        return (float(self.lr_init), float(self.lr_final) if self.lr_final else 0.0, float(self.max_steps) if self.max_steps else 0.0,
+                float(self.betas[0]), float(self.betas[1]), float(self.eps))
 
     def prepare_step(self) -> None:
         """Host bookkeeping of one captured step: makes sure the device-side step counter equals ``step_count`` (a stream-ordered
         fill with the value in the launch arguments, only after the host-side count was changed from outside: construction,
-        load_state_dict, a restored snapshot) and advances the host's mirror.  Call before replaying -- or capturing -- a graph
+        load_state_dict, a restored snapshot), that the device-side schedule constants are the host's current ones (lr_init,
+        lr_final, max_steps, betas, eps: six doubles, uploaded when they change -- a loaded param group or a manual lr drop reaches
+        the replays of a graph captured earlier), and advances the host's mirror.  Call before replaying -- or capturing -- a graph
         that contains ``step_staged``."""
         step_dev, _ = self._device_clock()
         if self._step_dev_expected != self.step_count:
             step_dev.fill_(int(self.step_count))
+        consts = self._schedule_constants()
+        if self._sched_uploaded != consts:
+            if not (consts[0] > 0.0 and 0.0 <= consts[3] < 1.0 and 0.0 <= consts[4] < 1.0):
+                raise ValueError(f"FlatAdam: need lr > 0 and betas in [0, 1), got lr {consts[0]}, betas {consts[3:5]}")
+            # (stream-ordered like the fill above: replays queued earlier still read the old constants)
+            self._sched_dev.copy_(torch.tensor(consts, dtype=torch.float64), non_blocking=False)
+            self._sched_uploaded = consts
         self.step_count += 1
         self._step_dev_expected = self.step_count
 
     def step_staged(self, grad_scale: float = 1.0) -> None:
-        """Device clock tick + the Adam update with the scalars it derived (lse_adam_schedule_dev, lse_adam_step_dev): capturable."""
+        """Device clock tick + the Adam update with the scalars it derived (lse_adam_schedule_dev, lse_adam_step_dev): capturable.
+        Nothing step- or schedule-dependent is a launch argument: a captured pair follows ``prepare_step``'s device-side state."""
         step_dev, hyper = self._device_clock()
-        ops.adam_schedule_dev(step_dev, hyper, self.lr_init, self.lr_final, self.max_steps, self.betas[0], self.betas[1])
-        ops.adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, hyper, self.betas[0],
-                          self.betas[1], self.eps, grad_scale)
+        ops.adam_schedule_dev(step_dev, hyper, self._sched_dev)
+        ops.adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, hyper, grad_scale)
 
     # -- resume (nerfstudio saves ``optimizers: {"fields": optimizer.state_dict()}``, R:lse_nerf/lse_trainer.py:85-122) ------
     def state_dict(self) -> dict:

@@ -1,5 +1,5 @@
 """Training fast path without host read-backs of the sample counts (LSENeRFModel.deferred_counts -> LSEOccGridEstimator.sampling
-(deferred=True) -> lse_set_device_count): the packed arrays have capacity extent, the counts stay on the device, every
+(deferred=True) -> the n_dev argument of the per-sample entry points): the packed arrays have capacity extent, the counts stay on the device, every
 per-sample kernel clamps to them.  Values must be those of the synchronising path: renders and sample counts bit for bit (same
 kernels on the same samples), gradients up to the order of float-atomic summation."""
 import pytest

@@ -42,7 +42,7 @@ def test_traverse_bit_exact(levels, res, cone, step):
 
 
 def test_traverse_fma_setup_is_bit_exact_against_the_fma_oracle():
-    """Option "traverse_fma": the a*b+c sites of the traversal set-up as fused multiply-adds, i.e. what nvcc's default
+    """Call flag LSE_TRAVERSE_FMA_SETUP (``fma_setup=True``): the a*b+c sites of the traversal set-up as fused multiply-adds, i.e. what nvcc's default
     contraction makes of nerfacc's grid.cu.  1024 sphere rays through a carved 4-level 128^3 grid with cone-angle steps (the
     workload on which the two arithmetic conventions differ in about one interval per million,
     tests/test_oracle_cpu.py::test_fma_contraction_changes_few_sample_intervals): the kernel with the option on equals the FMA
@@ -60,17 +60,13 @@ def test_traverse_fma_setup_is_bit_exact_against_the_fma_oracle():
     step = float(np.float32(2 * np.sqrt(3.0) / 1000))
     near, far = torch.full((R,), 0.05), torch.full((R,), 1e3)
     b = torch.rand(4, 128, 128, 128, generator=g) < 0.43
-    try:
-        for fma in (1, 0):
-            _lib.set_option("traverse_fma", fma)
-            ri, ts, te, packed = osamp.traverse_grids(o, d, b, aabbs, near, far, step, 0.004, fma=bool(fma))
-            hri, hts, hte, hpacked = ops.traverse_grids(o.cuda(), d.cuda(), b.cuda().view(torch.uint8), aabbs.cuda(), near.cuda(),
-                                                        far.cuda(), step, 0.004)
-            assert ri.numel() > 300_000
-            assert torch.equal(hpacked.cpu(), packed), fma
-            assert torch.equal(hri.cpu().long(), ri) and torch.equal(hts.cpu(), ts) and torch.equal(hte.cpu(), te), fma
-    finally:
-        _lib.set_option("traverse_fma", 0)
+    for fma in (1, 0):        # a call argument since ABI 5 (LSE_TRAVERSE_FMA_SETUP): nothing to set, nothing to restore
+        ri, ts, te, packed = osamp.traverse_grids(o, d, b, aabbs, near, far, step, 0.004, fma=bool(fma))
+        hri, hts, hte, hpacked = ops.traverse_grids(o.cuda(), d.cuda(), b.cuda().view(torch.uint8), aabbs.cuda(), near.cuda(),
+                                                    far.cuda(), step, 0.004, fma_setup=bool(fma))
+        assert ri.numel() > 300_000
+        assert torch.equal(hpacked.cpu(), packed), fma
+        assert torch.equal(hri.cpu().long(), ri) and torch.equal(hts.cpu(), ts) and torch.equal(hte.cpu(), te), fma
 
 
 @pytest.mark.parametrize("levels,res,cone,step", [(1, 32, 0.0, 0.01), (4, 32, 0.004, 0.005), (4, 128, 0.0, 0.0034641)])
@@ -297,7 +293,7 @@ def _hash_bwd_ex(ops, meta, x, dy, table, with_dx=True, **opt_kw):
         o.workspace, o.workspace_bytes = ws.data_ptr(), nbytes
     P = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
     _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x), P(dy), P(table), P(dt), P(dx), 0, 0, meta.n_levels, x.shape[0],
-              ctypes.byref(o), ops._stream())
+              None, ctypes.byref(o), ops._stream())
     assert not bool(ws.any()), "the replica workspace must read zero again after the call"
     return dt, dx
 
@@ -348,13 +344,34 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
     for sc in meta.scales:
         p = x.double() * sc + 0.5
         on_face |= ((p - p.round()).abs() < 1e-4).any(-1)
-    for name, kw in variants.items():
+    from lsenerf_amd import _lib
+
+    def check(name, kw):
         dt, dx = _hash_bwd_ex(ops, meta, xg, dy, tg, **kw)
         assert nmax_err(dt, tc.grad) < TOL_GRAD, name
         blk = blockwise_nmax_err(dt, tc.grad, bounds)
         assert blk < TOL_GRAD_BLOCK, (name, blk)
         assert rel_l2(dt, tc.grad) < TOL_GRAD, name
         assert nmax_err(dx.cpu()[~on_face], xc.grad[~on_face]) < TOL_GRAD, name
+
+    # The library that ships holds the production kernels only (ABI 5): the batched sector-cache kernel with the second-generation
+    # flush (impl 2, gran 6) under any staging / probing / few-runs / replica setting, and the generic 16-lanes-per-sample kernel.
+    # Every other selection is a development variant: rejected there, held against the oracle in liblse_hip_dev.so.
+    shipped = lambda kw: (kw.get("impl", 2) == 0 or (kw.get("impl", 2) == 2 and kw.get("gran", 6) == 6 and not kw.get("prefetch"))) \
+        and not kw.get("coarse_levels") and kw.get("rounds", 32) == 32
+    n_shipped = 0
+    for name, kw in variants.items():
+        if shipped(kw):
+            check(name, kw)
+            n_shipped += 1
+        else:
+            with pytest.raises(_lib.LseHipError, match="development variant"):
+                _hash_bwd_ex(ops, meta, xg, dy, tg, **kw)
+    assert n_shipped >= 14
+    assert _lib.dev_available(), "liblse_hip_dev.so is built by __graft_entry__.build() (make -C lsenerf_amd/csrc dev)"
+    with _lib.dev_library():
+        for name, kw in variants.items():
+            check("dev:" + name, kw)
 
 
 def test_hash_full_size_forward_subset_and_backward_linearity():
@@ -416,15 +433,15 @@ def test_hash_bwd_level_ranges_add_up():
     desc = meta.desc()
     P = lambda t_: ctypes.c_void_p(t_.data_ptr())
     full_t, full_x = torch.zeros_like(table), torch.empty_like(x)
-    _lib.call("lse_hash_bwd", ctypes.byref(desc), P(x), P(dy), P(table), P(full_t), P(full_x), N, ops._stream())
+    _lib.call("lse_hash_bwd", ctypes.byref(desc), P(x), P(dy), P(table), P(full_t), P(full_x), N, None, ops._stream())
     part_t, part_x = torch.zeros_like(table), torch.full_like(x, 7.0)     # first launch overwrites d(x)
-    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 6, 16, N, ops._stream())
+    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 6, 16, N, None, ops._stream())
     lo = 2 * meta.offsets[6]
     assert float(part_t[:lo].abs().max()) == 0.0 and float(part_t[lo:].abs().max()) > 0
-    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 1, 0, 6, N, ops._stream())
+    _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 1, 0, 6, N, None, ops._stream())
     assert nmax_err(part_t, full_t) < TOL_GRAD and nmax_err(part_x, full_x) < TOL_GRAD
     with pytest.raises(_lib.LseHipError):
-        _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 9, 3, N, ops._stream())
+        _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), P(x), P(dy), P(table), P(part_t), P(part_x), 0, 9, 3, N, None, ops._stream())
 
 
 def test_hash_partition_of_unity_and_linearity_full_size():
@@ -446,7 +463,7 @@ def test_hash_partition_of_unity_and_linearity_full_size():
 
 
 # ------------------------------------------------------------------------------------------------ MLP
-def _mlp_case(in_dim, width, num_layers, out_dim, act, level_major, N, use_bias, seed=0):
+def _mlp_case(in_dim, width, num_layers, out_dim, act, level_major, N, use_bias, seed=0, arith=0):
     from oracle.field import TcnnMLP
     from lsenerf_amd import _lib
     ops = _ops()
@@ -476,7 +493,7 @@ def _mlp_case(in_dim, width, num_layers, out_dim, act, level_major, N, use_bias,
     if act == "Sigmoid":
         out_ref = torch.sigmoid(out_ref)
     meta = ops.MlpMeta(in_dim, width, num_layers - 1, _lib.LSE_ACT_SIGMOID if act == "Sigmoid" else _lib.LSE_ACT_NONE,
-                       _lib.LSE_IN_LEVELMAJOR if level_major else _lib.LSE_IN_ROWMAJOR)
+                       _lib.LSE_IN_LEVELMAJOR if level_major else _lib.LSE_IN_ROWMAJOR, arith=arith)
     pg = params.clone().cuda().requires_grad_(True)
     if level_major:
         xin = x.view(N, in_dim // 2, 2).permute(1, 0, 2).contiguous().cuda().requires_grad_(True)
@@ -530,24 +547,21 @@ def test_mlp_first_hidden_layer_recomputed_or_saved(monkeypatch, recompute):
     _mlp_case(16, 32, 3, 16, None, False, 777, True, seed=8)
 
 
-@pytest.mark.parametrize("recompute_all,fwd_impl", [(True, 2), (True, 1), (False, 2)])
-def test_mlp_third_generation_bf16_pieces(monkeypatch, recompute_all, fwd_impl):
+@pytest.mark.parametrize("recompute_all,f32_mfma_fwd", [(True, False), (True, True), (False, False)])
+def test_mlp_third_generation_bf16_pieces(monkeypatch, recompute_all, f32_mfma_fwd):
     """lsenerf_amd/csrc/mlp_x6.h: f32 operands cut into three bf16 pieces, six piece products per multiply on the bf16 matrix
-    cores (f32-equivalent error bound -> the SAME tolerances as the f32-MFMA kernels), forward (mlp_fwd_impl = 2) and the
-    backward that recomputes every hidden layer (act_tiled = 3), head and base shapes, ragged sizes, rows of every length."""
+    cores (f32-equivalent error bound -> the SAME tolerances as the f32-MFMA kernels), forward (lse_mlp_desc.arith = AUTO; the
+    f32-MFMA forward through arith = LSE_MLP_ARITH_F32_MFMA, a call argument since ABI 5) and the backward that recomputes every
+    hidden layer (act_tiled = 3), head and base shapes, ragged sizes, rows of every length."""
     from lsenerf_amd import _lib
     ops = _ops()
     monkeypatch.setattr(ops, "RECOMPUTE_ALL", recompute_all)
-    old = _lib.get_option("mlp_fwd_impl")
-    _lib.set_option("mlp_fwd_impl", fwd_impl)
-    try:
-        for n in (1, 17, 31, 32, 33, 2051, 9000):
-            _mlp_case(16, 64, 3, 16, "Sigmoid", False, n, True, seed=20 + n)
-            _mlp_case(16, 64, 3, 16, None, False, n, False, seed=21 + n)
-            _mlp_case(32, 64, 2, 16, None, True, n, False, seed=22 + n)
-        _mlp_case(32, 64, 2, 16, None, False, 1500, False, seed=23)      # row-major 32-wide input
-    finally:
-        _lib.set_option("mlp_fwd_impl", old)
+    arith = _lib.LSE_MLP_ARITH_F32_MFMA if f32_mfma_fwd else _lib.LSE_MLP_ARITH_AUTO
+    for n in (1, 17, 31, 32, 33, 2051, 9000):
+        _mlp_case(16, 64, 3, 16, "Sigmoid", False, n, True, seed=20 + n, arith=arith)
+        _mlp_case(16, 64, 3, 16, None, False, n, False, seed=21 + n, arith=arith)
+        _mlp_case(32, 64, 2, 16, None, True, n, False, seed=22 + n, arith=arith)
+    _mlp_case(32, 64, 2, 16, None, False, 1500, False, seed=23, arith=arith)      # row-major 32-wide input
 
 
 @pytest.mark.parametrize("head", [True, False])
@@ -579,19 +593,15 @@ def test_bf16_piece_arithmetic_has_the_error_level_of_f32(head):
         h = torch.relu(x.double() @ params[:2048].view(64, 32).double().T)
         ref = h @ params[2048:].view(16, 64).double().T
         xin = x.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda()
-    desc = meta.desc()
+    import dataclasses
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     pc, bc, rc = params.cuda(), (bias.cuda() if head else None), (ridx.cuda() if head else None)
     errs = {}
-    old = _lib.get_option("mlp_fwd_impl")
-    try:
-        for impl in (1, 2):
-            _lib.set_option("mlp_fwd_impl", impl)
-            out = torch.empty(N, 16, device="cuda")
-            _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(pc), P(xin), P(bc), P(rc), P(out), 16, None, 1, None, None, 0.0, N, ops._stream())
-            errs[impl] = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
-    finally:
-        _lib.set_option("mlp_fwd_impl", old)
+    for impl, arith in ((1, _lib.LSE_MLP_ARITH_F32_MFMA), (2, _lib.LSE_MLP_ARITH_AUTO)):     # the route is part of the descriptor
+        desc = dataclasses.replace(meta, arith=arith).desc()
+        out = torch.empty(N, 16, device="cuda")
+        _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(pc), P(xin), P(bc), P(rc), P(out), 16, None, 1, None, None, 0.0, N, None, ops._stream())
+        errs[impl] = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
     assert errs[1] < 1e-6 and errs[2] < 1e-6, errs
     assert errs[2] <= 2 * errs[1] + 1e-7, errs
 
@@ -621,31 +631,26 @@ def test_bf16_piece_arithmetic_on_extreme_and_non_finite_inputs():
     def run(xx):
         xin = xx.view(N, 16, 2).permute(1, 0, 2).contiguous().cuda()
         out = torch.empty(N, 16, device="cuda")
-        _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(params), P(xin), None, None, P(out), 16, None, 1, None, None, 0.0, N, ops._stream())
+        _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(params), P(xin), None, None, P(out), 16, None, 1, None, None, 0.0, N, None, ops._stream())
         return out.cpu()
     pd = params.double().cpu()
     ref = torch.relu(x.double() @ pd[:2048].view(64, 32).T) @ pd[2048:].view(16, 64).T
-    old = _lib.get_option("mlp_fwd_impl")
-    try:
-        _lib.set_option("mlp_fwd_impl", 2)
-        base = run(x)
-        assert float((base.double() - ref).abs().max() / ref.abs().max()) < 1e-6
-        for e in (60, -60):
-            sc = float(2.0 ** e)
-            out = run(x * sc)
-            assert torch.isfinite(out).all(), e
-            err = float((out.double() / sc - ref).abs().max() / ref.abs().max())
-            assert err < 1e-6, (e, err)
-        bad = x.clone()
-        bad[100, 3] = float("inf")
-        bad[2000, 17] = float("nan")
-        out = run(bad)
-        assert float(out[100].abs().max()) == 0.0 and float(out[2000].abs().max()) == 0.0
-        keep = torch.ones(N, dtype=torch.bool)
-        keep[100] = keep[2000] = False
-        assert torch.equal(out[keep], base[keep])
-    finally:
-        _lib.set_option("mlp_fwd_impl", old)
+    base = run(x)
+    assert float((base.double() - ref).abs().max() / ref.abs().max()) < 1e-6
+    for e in (60, -60):
+        sc = float(2.0 ** e)
+        out = run(x * sc)
+        assert torch.isfinite(out).all(), e
+        err = float((out.double() / sc - ref).abs().max() / ref.abs().max())
+        assert err < 1e-6, (e, err)
+    bad = x.clone()
+    bad[100, 3] = float("inf")
+    bad[2000, 17] = float("nan")
+    out = run(bad)
+    assert float(out[100].abs().max()) == 0.0 and float(out[2000].abs().max()) == 0.0
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[100] = keep[2000] = False
+    assert torch.equal(out[keep], base[keep])
 
 
 @pytest.mark.parametrize("pattern", ["short", "mixed", "tile_aligned", "long"])
@@ -1038,30 +1043,31 @@ def test_mlp_fused_density_head_and_compact_output():
 
 
 def test_hash_fwd_lds_resident_variant_is_bit_identical():
-    """Option hash_fwd_lds_levels (the "LDS-staged trilinear interpolation" BASELINE.json's north_star names, kept as the A/B partner
+    """Development knob hash_fwd_lds_levels (the "LDS-staged trilinear interpolation" BASELINE.json's north_star names, kept as the A/B partner
     of the L2-resident level-major schedule, profiles/r04_hash_fwd_lds_ab.txt): the k coarsest levels are gathered from an LDS copy of
     their table.  Same multiply-adds in the same order -> bit-identical features, for ragged counts, a device-side count below the
     capacity, and a grid whose level 1 does not fit the LDS (the variant then stops at level 0)."""
     from lsenerf_amd import _lib, ops
     g = torch.Generator().manual_seed(5)
-    try:
+    with _lib.dev_library() as dev:        # a knob of the development build (csrc/dev_knobs.h); restored when the block ends
         for meta, n in ((ops.make_grid_meta(), 200003), (ops.make_grid_meta(n_levels=4, log2_hashmap_size=12), 777),
                         (ops.make_grid_meta(base_resolution=24, max_res=1024), 65537)):
             table = ((torch.rand(meta.n_params, generator=g) * 2 - 1) * 1e-2).cuda()
             x = torch.rand(n, 3, generator=g).cuda()
             x[: n // 2] = (x[:1] + 1e-3 * torch.arange(n // 2, device="cuda")[:, None]).clamp(0, 1)      # ray-like: neighbours share cells
-            _lib.set_option("hash_fwd_lds_levels", 0)
+            dev.set_option("hash_fwd_lds_levels", 0)
             ref = ops.hash_encode(x, table, meta)
             n_dev = torch.tensor([n - 1234 if n > 2000 else n - 7], dtype=torch.int64, device="cuda")
             ref_dev = ops.hash_encode(x, table, meta, n_dev=n_dev)
             for k in (1, 2, 5):
-                _lib.set_option("hash_fwd_lds_levels", k)
+                dev.set_option("hash_fwd_lds_levels", k)
                 assert torch.equal(ops.hash_encode(x, table, meta), ref), (meta.n_levels, n, k)
                 got = ops.hash_encode(x, table, meta, n_dev=n_dev)
                 m = int(n_dev)
                 assert torch.equal(got[:, :m], ref_dev[:, :m]) and torch.equal(got[:, :m], ref[:, :m]), (meta.n_levels, n, k)
-    finally:
-        _lib.set_option("hash_fwd_lds_levels", 0)
+            dev.set_option("hash_fwd_lds_levels", 0)
+    # ... and the library that ships computes the same bits as the development build's default schedule
+    assert torch.equal(ops.hash_encode(x, table, meta), ref)
 
 
 @pytest.mark.parametrize("shape", ["head", "base"])
@@ -1171,7 +1177,7 @@ def test_compact_features_equals_boolean_indexing_for_every_level_grouping():
     from lsenerf_amd import _lib
     ops = _ops()
     g = torch.Generator(device="cuda").manual_seed(2)
-    try:
+    with _lib.dev_library() as dev:
         for L, R in ((16, 257), (5, 33), (1, 7)):
             cnt = torch.randint(0, 200, (R,), device="cuda", generator=g)
             cnt[::7] = 0                                                      # rays that missed every occupied cell
@@ -1187,8 +1193,24 @@ def test_compact_features_equals_boolean_indexing_for_every_level_grouping():
             sel = (torch.rand(N, device="cuda", generator=g) < 0.9).to(torch.uint8)
             y = torch.randn(L, N, 2, device="cuda", generator=g)
             for groups in (1, 2, 3, 4, 16):
-                _lib.set_option("compact_features_groups", groups)
+                dev.set_option("compact_features_groups", groups)
                 ox, os_, oy = ops.compact_features(keep.to(torch.uint8).contiguous(), packed, new_packed, n_new, x01, sel, y)
                 assert torch.equal(ox, x01[keep]) and torch.equal(os_, sel[keep]) and torch.equal(oy, y[:, keep]), (L, R, groups)
-    finally:
-        _lib.set_option("compact_features_groups", 4)
+                if groups == 4:      # the shipped library's constant: same result from liblse_hip.so
+                    with _ShippedLibrary():
+                        ox, os_, oy = ops.compact_features(keep.to(torch.uint8).contiguous(), packed, new_packed, n_new, x01, sel, y)
+                        assert torch.equal(ox, x01[keep]) and torch.equal(os_, sel[keep]) and torch.equal(oy, y[:, keep]), (L, R)
+
+
+class _ShippedLibrary:
+    """Inside a dev_library() block: back to liblse_hip.so for a few calls."""
+
+    def __enter__(self):
+        from lsenerf_amd import _lib
+        self._inner, _lib._lib = _lib._lib, _lib._prod_lib
+        return self
+
+    def __exit__(self, *exc):
+        from lsenerf_amd import _lib
+        _lib._lib = self._inner
+        return False

@@ -17,6 +17,12 @@ def header_functions():
     return sorted(set(re.findall(r"\b(lse_[a-z0-9_]+)\s*\(", src)))
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("lse_")}
+
+
 def test_library_exports_every_declared_symbol():
     from lsenerf_amd import _lib
     lib = _lib.load()
@@ -26,29 +32,61 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
     assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts", "lse_hash_bwd_workspace_bytes"} == set(names)
-    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 4
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 5
 
 
-def test_runtime_options_and_hash_bwd_opts_without_gpu():
-    """Tuning knobs are call arguments (lse_hash_bwd_ex) or run-time options -- no process-lifetime environment statics."""
+def test_the_shipped_library_has_no_state_to_set():
+    """ABI 5 (include/lse_hip.h, "NO GLOBAL OR THREAD-LOCAL STATE"): the exported symbols of liblse_hip.so are exactly the header's
+    functions -- no lse_set_device_count (the device-side count is the `n_dev` argument of the per-sample entry points), no
+    lse_set_option / lse_get_option (tuning knobs are constants; the development build liblse_hip_dev.so, csrc/dev_knobs.h, adds
+    exactly those two).  The header says so in as many words."""
+    from lsenerf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "lse_hip.h")).read()
+    assert "NO GLOBAL OR THREAD-LOCAL STATE" in hdr
+    for gone in ("lse_set_device_count", "lse_set_option", "lse_get_option"):
+        assert gone + "(" not in re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), gone
+    shipped = _exported(_lib.LIB_PATH)
+    assert shipped == set(header_functions()), shipped ^ set(header_functions())
+    assert _lib.dev_available(), "liblse_hip_dev.so is built by __graft_entry__.build() (make -C lsenerf_amd/csrc dev)"
+    assert _exported(_lib.DEV_LIB_PATH) == shipped | {"lse_set_option", "lse_get_option"}
+    # the per-sample entry points carry the count themselves
+    src = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name in ("lse_positions_fwd", "lse_positions_bwd", "lse_hash_fwd", "lse_hash_bwd", "lse_hash_bwd_levels", "lse_hash_bwd_ex",
+                 "lse_mlp_fwd", "lse_mlp_bwd"):
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m and "const int64_t *n_dev" in m.group(1), name
+    with pytest.raises(_lib.LseHipError, match="development build"):
+        _lib.set_option("mlp_fwd_cfg", 44)
+
+
+def test_dev_knobs_and_hash_bwd_opts_without_gpu():
+    """Kernel selections are call arguments (lse_hash_bwd_ex's options, lse_mlp_desc.arith, traversal flags); the development
+    build's knobs are writable inside ``_lib.dev_library()`` only and restored when the block ends."""
     from lsenerf_amd import _lib
     o = _lib.hash_bwd_default_opts()
     assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 6, 3, 32, 0, 16, 0)
     assert (o.replicas, o.replica_levels, o.prefetch, o.workspace) == (16, 4, 0, None)
-    assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28 and _lib.get_option("traverse_fma") == 0
-    _lib.set_option("mlp_fwd_cfg", 44)
-    assert _lib.get_option("mlp_fwd_cfg") == 44
-    _lib.set_option("mlp_fwd_cfg", 28)
-    with pytest.raises(_lib.LseHipError):
-        _lib.set_option("no_such_option", 1)
-    # invalid kernel selections are rejected before anything is launched
-    import ctypes
+    with _lib.dev_library() as dev:
+        assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28 and _lib.get_option("traverse_vec") == 1
+        dev.set_option("mlp_fwd_cfg", 44)
+        assert _lib.get_option("mlp_fwd_cfg") == 44
+        dev.set_option("hash_bwd_few_runs", 9)
+        assert _lib.hash_bwd_default_opts().few_runs == 9           # (the dev build's defaults follow its knobs)
+        with pytest.raises(_lib.LseHipError):
+            _lib.set_option("no_such_option", 1)
+    with _lib.dev_library():
+        assert _lib.get_option("mlp_fwd_cfg") == 28 and _lib.get_option("hash_bwd_few_runs") == 6      # restored on exit
+    assert _lib.hash_bwd_default_opts().few_runs == 6
+    # invalid kernel selections are rejected before anything is launched; development variants are not in the shipped library
     d = _lib.GridDesc()
     d.n_levels, d.n_features = 1, 2
     d.offsets[0], d.offsets[1], d.scales[0], d.resolutions[0] = 0, 8, 1.0, 2
     o.impl = 7
     with pytest.raises(_lib.LseHipError):
-        _lib.call("lse_hash_bwd_ex", ctypes.byref(d), None, None, None, None, None, 0, 0, 1, 0, ctypes.byref(o), None)
+        _lib.call("lse_hash_bwd_ex", ctypes.byref(d), None, None, None, None, None, 0, 0, 1, 0, None, ctypes.byref(o), None)
+    o.impl = 1
+    with pytest.raises(_lib.LseHipError, match="development variant"):
+        _lib.call("lse_hash_bwd_ex", ctypes.byref(d), None, None, None, None, None, 0, 0, 1, 0, None, ctypes.byref(o), None)
 
 
 def test_argument_counts_match_header():
@@ -65,7 +103,7 @@ def test_argument_counts_match_header():
 def test_descriptor_struct_layouts():
     from lsenerf_amd import _lib
     assert ctypes.sizeof(_lib.GridDesc) == 4 + 4 + 33 * 4 + 32 * 4 + 32 * 4
-    assert ctypes.sizeof(_lib.MlpDesc) == 32
+    assert ctypes.sizeof(_lib.MlpDesc) == 36
 
 
 def test_invalid_arguments_fail_loudly_without_gpu():
@@ -73,15 +111,15 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     from lsenerf_amd import _lib
     lib = _lib.load()
     d = _lib.MlpDesc(24, 64, 1, 0, 0)
-    rc = lib.lse_mlp_fwd(ctypes.byref(d), None, None, None, None, None, 16, None, 0, None, None, 0.0, 8, None)
+    rc = lib.lse_mlp_fwd(ctypes.byref(d), None, None, None, None, None, 16, None, 0, None, None, 0.0, 8, None, None)
     assert rc == -1 and b"n_in" in lib.lse_last_error()
     g = _lib.GridDesc()
     g.n_levels, g.n_features = 16, 4
-    rc = lib.lse_hash_fwd(ctypes.byref(g), None, None, None, 8, None)
+    rc = lib.lse_hash_fwd(ctypes.byref(g), None, None, None, 8, None, None)
     assert rc == -1 and b"n_features" in lib.lse_last_error()
     with pytest.raises(_lib.LseHipError):
         _lib.call("lse_traverse_grids", None, None, 4, None, None, 1, 8, 8, 8, None, None, 0.1, 0.0, 0, None, None, None,
-                  None, None, None)
+                  None, None, 0, None)
     # zero-sized work is a no-op, not an error
     assert lib.lse_volrend_fwd(None, None, None, None, 0, None, 0, None, None, None, None, None) == 0
 

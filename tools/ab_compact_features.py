@@ -3,6 +3,7 @@
 of waves per ray (option compact_features_groups), at the size of the reference's default configuration: 3510 rays x ~355 candidate
 samples, ~70 % kept.  Outputs must be identical; interleaved rounds in one process."""
 import os, sys
+os.environ.setdefault("LSE_DEV", "1")      # tuning knobs exist in the development build only (csrc/dev_knobs.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from lsenerf_amd import ops, _lib

@@ -4,6 +4,7 @@
 positions: whole lse_hash_fwd, interleaved rounds in one process, outputs compared bit for bit.
 usage: python tools/ab_hash_fwd_lds.py [out.txt]"""
 import os, sys
+os.environ.setdefault("LSE_DEV", "1")      # tuning knobs exist in the development build only (csrc/dev_knobs.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LSE_DEV=1      # LSE_OPT_* knobs exist in the development build only (liblse_hip_dev.so, csrc/dev_knobs.h)
 # Defaults of the hash backward (run-time options hash_bwd_few_runs / hash_bwd_stage_max / hash_bwd_probes) on every regime bench.py
 # measures.  usage: bash tools/ab_hash_opts.sh <out file> "FEW_RUNS=8" "FEW_RUNS=8 STAGE_MAX=24" ...
 OUT=$1; shift; mkdir -p $(dirname $OUT)

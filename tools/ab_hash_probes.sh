@@ -1,4 +1,5 @@
 #!/bin/bash
+export LSE_DEV=1      # LSE_OPT_* knobs exist in the development build only (liblse_hip_dev.so, csrc/dev_knobs.h)
 # Probe rounds of the hash backward's sector cache (option hash_bwd_probes) on every regime bench.py measures.  usage: ... <out file>
 OUT=$1; shift; mkdir -p $(dirname $OUT)
 for v in "$@"; do

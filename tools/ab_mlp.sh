@@ -1,4 +1,5 @@
 #!/bin/bash
+export LSE_DEV=1      # LSE_OPT_* knobs exist in the development build only (liblse_hip_dev.so, csrc/dev_knobs.h)
 # A/B the MLP kernel configurations (CT*10+NW): correctness (pytest -k mlp) then per-step kernel times from bench.py
 for cfg in 44 28; do
   export LSE_OPT_MLP_FWD_CFG=$cfg LSE_OPT_MLP_BWD_CFG=$cfg

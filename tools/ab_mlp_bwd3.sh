@@ -1,4 +1,5 @@
 #!/bin/bash
+export LSE_DEV=1      # LSE_OPT_* knobs exist in the development build only (liblse_hip_dev.so, csrc/dev_knobs.h)
 # A/B the third-generation MLP backward configurations (mlp_bwd3_cfg = CT * 100 + NW): parity tests, then per-step kernel times.
 # usage: bash tools/ab_mlp_bwd3.sh <out dir> cfg...
 OUT=$1; shift; mkdir -p $OUT

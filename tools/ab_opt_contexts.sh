@@ -1,4 +1,5 @@
 #!/bin/bash
+export LSE_DEV=1      # LSE_OPT_* knobs exist in the development build only (liblse_hip_dev.so, csrc/dev_knobs.h)
 # A/B one run-time option of the library on the headline step AND the real-regime compositions (bench.py context keys):
 # usage: bash tools/ab_opt_contexts.sh <out file> <OPTION_NAME> v1 v2 ...
 OUT=$1; NAME=$2; shift 2; mkdir -p $(dirname $OUT)

@@ -46,7 +46,7 @@ def main():
         def bwd(with_dx=True):
             _lib.call("lse_hash_bwd", ctypes.byref(desc), ctypes.c_void_p(x01.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
                       ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(dtab.data_ptr()),
-                      ctypes.c_void_p(dx.data_ptr()) if with_dx else None, N, ops._stream())
+                      ctypes.c_void_p(dx.data_ptr()) if with_dx else None, N, None, ops._stream())
         med, mn = timeit(bwd)
         print(f"hash_bwd(dx) median {med:.3f} ms  min {mn:.3f} ms  -> {1024*N/med/1e6:.0f} GB/s algorithmic", flush=True)
         med, mn = timeit(lambda: bwd(False))
@@ -55,7 +55,7 @@ def main():
             def rng():
                 _lib.call("lse_hash_bwd_levels", ctypes.byref(desc), ctypes.c_void_p(x01.data_ptr()), ctypes.c_void_p(dy.data_ptr()),
                           ctypes.c_void_p(table.data_ptr()), ctypes.c_void_p(dtab.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
-                          0, lo, hi, N, ops._stream())
+                          0, lo, hi, N, None, ops._stream())
             med, mn = timeit(rng)
             print(f"hash_bwd levels [{lo},{hi}) median {med:.3f} ms", flush=True)
     if want("mlp"):

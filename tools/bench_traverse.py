@@ -16,7 +16,7 @@ for levels, S, occ in ((4, 1024, 1.0), (4, 128, 1.0), (1, 256, 1.0), (4, 1024, 0
             ctypes.c_void_p(est.aabbs.data_ptr()), levels, 128, 128, 128, ctypes.c_void_p(near.data_ptr()),
             ctypes.c_void_p(far.data_ptr()), float(step), 0.0)
     def count():
-        _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, ops._stream())
+        _lib.call("lse_traverse_grids", *args, 0, ctypes.c_void_p(cnts.data_ptr()), None, None, None, None, 0, ops._stream())
     for _ in range(3): count()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -92,7 +92,7 @@ def make_hash_bwd(lo, hi):
     keep = (xs, dy, dt, dx, ws, o)
 
     def run():
-        _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(xs), P(dy), P(table), P(dt), P(dx), 0, 0, 16, m, ctypes.byref(o), ops._stream())
+        _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(xs), P(dy), P(table), P(dt), P(dx), 0, 0, 16, m, None, ctypes.byref(o), ops._stream())
     return run, keep
 
 

@@ -29,7 +29,7 @@ for k, v in [a.split("=") for a in sys.argv[1:]]:
     setattr(opts, k, int(v))
 def run(lo, hi):
     f = lambda: _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, lo, hi, n,
-                          ctypes.byref(opts), ops._stream())
+                          None, ctypes.byref(opts), ops._stream())
     return timeit(f, iters=7, warm=2)[0]
 prev = 0.0
 print("k   t[0,k)   marginal   t[k,16)")

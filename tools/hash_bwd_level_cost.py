@@ -85,7 +85,7 @@ def level_time(x01, dy, level, **opt_kw):
     dt = torch.zeros_like(table)
     dx = torch.empty_like(x01)
     f = lambda: _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, level, level + 1, n,
-                          ctypes.byref(o), ops._stream())
+                          None, ctypes.byref(o), ops._stream())
     return timeit(f, iters=7, warm=2)[0]
 
 
@@ -106,7 +106,7 @@ for name, x01 in regimes.items():
             setattr(o, k, v)
         dt = torch.zeros_like(table); dx = torch.empty_like(x01)
         f = lambda: _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, meta.n_levels, n,
-                              ctypes.byref(o), ops._stream())
+                              None, ctypes.byref(o), ops._stream())
         full[label] = timeit(f, iters=7, warm=2)[0]
     print(f"\n== {name}: N = {n} samples ({n / R:.0f} per ray); all 16 levels: default kernel {full['default']:.3f} ms "
           f"({full['default'] * 1e6 / n:.3f} ns/sample), 16-lane kernel {full['lanes16']:.3f} ms", flush=True)

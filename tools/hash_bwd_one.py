@@ -63,7 +63,7 @@ if nb:
     ws = torch.zeros(nb // 4, dtype=torch.float32, device=dev)
     o_.workspace, o_.workspace_bytes = ws.data_ptr(), nb
 for _ in range(3):
-    _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, ctypes.byref(o_), ops._stream())
+    _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, None, ctypes.byref(o_), ops._stream())
 torch.cuda.synchronize()
 # distinct 64-byte lines of the gradient table per 64-sample window (= one wave of the kernel), per level: the request floor
 lines = []

@@ -76,7 +76,7 @@ for name, x01 in regimes.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), None if nodx else P(dx), 0, 0, 16, n,
-                      ctypes.byref(o), ops._stream())
+                      None, ctypes.byref(o), ops._stream())
             e1.record(); torch.cuda.synchronize()
             if rnd: times[v].append(e0.elapsed_time(e1))
     for v, _ in fns:

@@ -31,7 +31,7 @@ for l in range(meta.n_levels):
     d1.scales[0], d1.resolutions[0] = full.scales[l], full.resolutions[l]
     tab_l = table[2 * full.offsets[l]:2 * full.offsets[l + 1]]
     f = lambda: _lib.call("lse_hash_fwd", ctypes.byref(d1), ctypes.c_void_p(x01.data_ptr()), ctypes.c_void_p(tab_l.data_ptr()),
-                          ctypes.c_void_p(y1.data_ptr()), N, ops._stream())
+                          ctypes.c_void_p(y1.data_ptr()), N, None, ops._stream())
     med, mn = timeit(f)
     tot += med
     print(f"level {l:2d} res {full.resolutions[l]:5d}: {med:.4f} ms (all 8 XCDs on this level)", flush=True)

@@ -25,7 +25,7 @@ for name, meta, x, rb in (
     desc = meta.desc()
     def run(with_act):
         _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(params), P(x), P(rb), P(ridx), P(out), oc, P(act) if with_act else None, 1,
-                  None, None, 0.0, N, ops._stream())
+                  None, None, 0.0, N, None, ops._stream())
     a, _ = timeit(lambda: run(True))
     b, _ = timeit(lambda: run(False))
     flops = 2 * N * (meta.n_in * 64 + (meta.n_hidden_layers - 1) * 64 * 64 + 64 * 16)

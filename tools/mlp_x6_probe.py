@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused-MLP forward on the bf16 matrix cores with three-piece operands (mlp_x6.h, option mlp_fwd_impl = 2) next to the f32-MFMA
+"""Fused-MLP forward on the bf16 matrix cores with three-piece operands (mlp_x6.h, lse_mlp_desc.arith = AUTO) next to the f32-MFMA
 forward (impl 1): time at the metric size, and error of both against a float64 evaluation of the same network on a subset."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -53,23 +53,23 @@ for N in (4096 * 1024, 1000):
             rb = ridx = None
             params = torch.randn(meta.n_params, device=dev) * 0.15
             oc = 16
-        desc = meta.desc()
+        import dataclasses
         nl = meta.n_hidden_layers
         npad = (N + 15) // 16 * 16
         res = {}
         for impl in (1, 2):
-            _lib.set_option("mlp_fwd_impl", impl)
+            # (the arithmetic route is a descriptor field since ABI 5: 1 = f32 MFMA, 2 = bf16 pieces)
+            desc = dataclasses.replace(meta, arith=_lib.LSE_MLP_ARITH_F32_MFMA if impl == 1 else _lib.LSE_MLP_ARITH_AUTO).desc()
             out = torch.zeros(N, oc, device=dev)
             act = torch.zeros(nl, npad, 64, device=dev)
 
             def run():
                 _lib.call("lse_mlp_fwd", ctypes.byref(desc), P(params), P(x), P(rb), P(ridx), P(out), oc, P(act), 1,
-                          None, None, 0.0, N, ops._stream())
+                          None, None, 0.0, N, None, ops._stream())
             run()
             torch.cuda.synchronize()
             t = timeit(run)[0] if N > 100000 else float("nan")
             res[impl] = (out.clone(), act.clone(), t)
-        _lib.set_option("mlp_fwd_impl", 1)
         # float64 reference on a subset of rows
         M = min(N, 8192)
         rows = torch.randperm(N, device=dev)[:M]

@@ -40,7 +40,7 @@ cap = est._cap_per_ray(cfg.near_plane, cfg.far_plane, cfg.render_step_size, cfg.
 def march():
     return ops.traverse_grids_deferred(o, d, est._binaries_u8(), est.aabbs, near, far, cfg.render_step_size, cfg.cone_angle, cap)
 def hash_bwd():
-    _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, ctypes.byref(opts), ops._stream())
+    _lib.call("lse_hash_bwd_ex", ctypes.byref(desc), P(x01), P(dy), P(table), P(dt), P(dx), 0, 0, 16, n, None, ctypes.byref(opts), ops._stream())
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def timed(fn, iters=10):
     for _ in range(3): fn()
