@@ -299,7 +299,7 @@ def test_replays_issued_far_ahead_of_the_device_take_their_own_steps_scalars():
     opt.step_count = 5                               # e.g. resumed from a checkpoint
     opt.flat.grad.normal_()
     n = 64
-    log = torch.zeros(n + 8, 3, device="cuda")
+    log = torch.zeros(n + 8, 6, device="cuda")      # hyper = (lr, 1 - b1^t, 1 / sqrt(1 - b2^t), b1, b2, eps): all six live on the device
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -325,9 +325,22 @@ def test_replays_issued_far_ahead_of_the_device_take_their_own_steps_scalars():
         t = 6 + i                                    # the step this replay takes; its lr is that of `t - 1` finished steps
         f = min((t - 1) / 40, 1.0)
         lr = math.exp(math.log(1e-2) * (1 - f) + math.log(1e-4) * f)
-        want = (lr, 1 - 0.9 ** t, 1 / math.sqrt(1 - 0.999 ** t))
+        want = (lr, 1 - 0.9 ** t, 1 / math.sqrt(1 - 0.999 ** t), 0.9, 0.999, 1e-15)
         for a, b in zip(got[i].tolist(), want):
             assert abs(a - b) <= 2e-7 * abs(b), (i, got[i].tolist(), want)
+    # The schedule's constants are device-side state too (ABI 5: they were launch arguments, frozen into the captured graph):
+    # a param group loaded from a checkpoint, or a manual learning-rate drop, reaches the replays of the SAME graph.
+    opt.lr_init, opt.lr_final, opt.max_steps, opt.betas = 5e-3, 5e-5, 100, (0.8, 0.99)
+    opt.prepare_step()
+    graph.replay()
+    torch.cuda.synchronize()
+    t = 5 + n + 1
+    f = (t - 1) / 100
+    want = (math.exp(math.log(5e-3) * (1 - f) + math.log(5e-5) * f), 1 - 0.8 ** t, 1 / math.sqrt(1 - 0.99 ** t), 0.8, 0.99, 1e-15)
+    got = opt._hyper_dev.double().cpu().tolist()
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 2e-7 * abs(b), (got, want)
+    assert abs(opt.current_lr() - math.exp(math.log(5e-3) * (1 - t / 100) + math.log(5e-5) * t / 100)) < 1e-12     # host mirror agrees
 
 
 def test_capturing_a_step_survives_earlier_eager_graphs_of_the_same_model(capture_probe):
