@@ -208,14 +208,16 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
 /* Kernel selection of the hash backward as CALL ARGUMENTS (so that two variants can be compared inside one process):
  *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
  *                     levels batched into one cache pass (default); 1 = one cache pass per level; 0 = 16-lanes-per-sample kernel
- *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 16)
+ *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 48;
+ *                     32 is better when the step size is constant: profiles/r05_hash_bwd_thresholds.txt)
  *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2) =
  *                     512 sector slots PAIRED by 64-B line, flushed in slot order -- a float-atomic request costs the same for 4 .. 64
  *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request; 5 = the same with
  *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size);
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
  *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
- *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 6)
+ *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 8; 6 is better when
+ *                     the step size is constant)
  *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)
  *   interleave_from_scale  impl 0: levels with scale >= this use the interleaved sample mapping (default: never)

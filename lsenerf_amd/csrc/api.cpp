@@ -40,8 +40,8 @@ static const Option g_options[] = {
     {"mlp_bwd3_cfg", 208},
     {"mlp_act_nt", 0},
     {"hash_bwd_probes", 3},
-    {"hash_bwd_few_runs", 6},
-    {"hash_bwd_stage_max", 16},
+    {"hash_bwd_few_runs", 8},
+    {"hash_bwd_stage_max", 48},
     {"traverse_vec", 1},
 };
 

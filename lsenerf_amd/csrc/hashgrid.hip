@@ -1483,8 +1483,10 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
                            // when the queue is empty
     o->gran = 6;           // impl 2: 512 slots of one 32-B sector, paired by 64-B line, second-generation flush (4 = first-generation
                            // flush, 2 = unpaired); impl 1: 2 / 3
-    o->few_runs = (int32_t)lse::option("hash_bwd_few_runs");     // round 3 (replicas took the contention out of the direct adds): default configuration 1.60 -> 1.53 ms,
-                           // M-march 2.62 -> 2.62, M-packed 3.17 -> 3.20; 8: 1.51 / 2.63 / 3.28; 16: slower everywhere
+    o->few_runs = (int32_t)lse::option("hash_bwd_few_runs");     // 8 (round 5, profiles/r05_hash_bwd_thresholds.txt: with stage_max 48 the best pair for steps
+                           // that grow with the distance -- the reference's default configuration 1.51 -> 1.43 ms -- and neutral
+                           // (+0.2 %) at the metric size, whose constant step prefers (6, 32): 2.59 -> 2.56 ms; callers that know the
+                           // regime pass the pair (lsenerf_amd/ops.py: HASH_BWD_DENSE_STEPS); 10 and 16: slower everywhere)
     o->second_probe = (int32_t)lse::option("hash_bwd_probes");   // extra probe rounds (home + k * step) before a corner goes to memory
                            // alone; pays wherever the kernel is bound by atomic requests, costs ~2 % per round where it is issue-bound.
                            // 1 -> 3 rounds (round 3, once the later rounds probed NEW slots): requests 50.5 -> 48.2 M (metric size),

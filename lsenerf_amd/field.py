@@ -52,9 +52,20 @@ class Ed_HashEncoding(nn.Module):
         self.features_per_level = features_per_level
         self.log2_hashmap_size = log2_hashmap_size
         self.hash_table_size = 2 ** log2_hashmap_size
-        self.meta = ops.make_grid_meta(num_levels, features_per_level, log2_hashmap_size, min_res, max_res=max_res)
+        self._meta = ops.make_grid_meta(num_levels, features_per_level, log2_hashmap_size, min_res, max_res=max_res)
+        # sample regime of the rays this grid is trained on, set by the model from its sampler configuration (constant step vs
+        # steps that grow with the distance): selects the hash backward's path thresholds (ops.HASH_BWD_DENSE_STEPS)
+        self.dense_steps: bool = False
         # tcnn grid init U(-1e-4, 1e-4) (hash_init_scale only applies to the torch table the reference leaves dead)
         self.params = nn.Parameter((torch.rand(self.meta.n_params) * 2 - 1) * 1e-4)
+
+    @property
+    def meta(self) -> "ops.GridMeta":
+        import dataclasses
+        tuning = ops.HASH_BWD_DENSE_STEPS if self.dense_steps else ops.HASH_BWD_DEFAULT
+        if self._meta.bwd_tuning != tuning:
+            self._meta = dataclasses.replace(self._meta, bwd_tuning=tuning)
+        return self._meta
 
     def get_out_dim(self) -> int:
         return self.num_levels * self.features_per_level

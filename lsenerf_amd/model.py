@@ -500,6 +500,9 @@ class LSENeRFModel(nn.Module):
         num_rays = len(ray_bundle)
         fld = self.field
         rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        grid = getattr(fld, "mlp_base_grid", None)
+        if grid is not None and hasattr(grid, "dense_steps"):      # regime hint for the hash backward's path thresholds
+            grid.dense_steps = not (self.config.cone_angle and self.config.cone_angle > 0)
         sigma, h, _ = fld.density_packed(rays_o, rays_d, ray_idx, t_starts, t_ends, packed_info, n_dev)
         if fld.embedding_appearance is None:
             table, eidx = None, None

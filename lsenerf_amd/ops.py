@@ -76,6 +76,9 @@ class GridMeta:
     scales: Tuple[float, ...]
     resolutions: Tuple[int, ...]
     offsets: Tuple[int, ...]
+    # overrides of lse_hash_bwd_opts for this grid's backward, as ((field, value), ...): the caller's knowledge of the sample
+    # regime (HASH_BWD_DENSE_STEPS / HASH_BWD_DEFAULT below); call arguments of lse_hash_bwd_ex, nothing the library remembers
+    bwd_tuning: Tuple[Tuple[str, int], ...] = ()
 
     @property
     def n_entries(self):
@@ -467,6 +470,16 @@ def direct_grad_params(module: torch.nn.Module) -> Optional[dict]:
     return out or None
 
 
+# Path-selection thresholds of the hash backward by sample regime (profiles/r05_hash_bwd_thresholds.txt, MI355X): a wave that ends
+# <= few_runs runs at a level adds them straight to memory; a level that ends > stage_max runs passes the sector cache unstaged.
+#   constant step (cone_angle == 0: consecutive samples walk through cells at a fixed pace, the run-end count grows smoothly from
+#   level to level and the queue fills well): (6, 32) -- headline 2.59 -> 2.56 ms, inside-box 2.70 -> 2.63, M-packed +-0;
+#   steps that grow with the distance (cone_angle > 0, the reference's default: sparser samples, more run ends per level):
+#   (8, 48) = the library's defaults -- default configuration 1.51 -> 1.43 ms.
+HASH_BWD_DENSE_STEPS = (("few_runs", 6), ("stage_max", 32))
+HASH_BWD_DEFAULT = ()
+
+
 _HASH_BWD_WS = {}      # (device index, stream) -> zeroed workspace of the hash backward's coarse-level replicas
 
 
@@ -511,6 +524,8 @@ class _HashFn(torch.autograd.Function):
         dx = torch.empty_like(x01) if ctx.needs_input_grad[0] else None
         desc = meta.desc()
         opts = hash_bwd_opts_with_workspace(desc, x01.device)     # defaults + the coarse-level replica workspace
+        for k, v in meta.bwd_tuning:                              # the caller's regime hint (call arguments, not library state)
+            setattr(opts, k, v)
         hooks = _hash_bwd_hooks_of(table)      # per TABLE, not per process: other models in the process are untouched
         split = hooks.get("split") if hooks else None
         if hooks and hooks.get("before") is not None:     # e.g. fork a side stream here: the scatter below is the last big kernel of the backward pass

@@ -236,3 +236,32 @@ def test_main_pass_reuses_the_prepass_features_of_the_survivors():
         hip.field.mlp_base_grid.params.mul_(1.0)       # in-place update bumps the version: features are stale
     ts, te = rs.frustums.starts[..., 0], rs.frustums.ends[..., 0]
     assert hip.field._take_prepass(rb.origins, rb.directions, rs.ray_indices, ts) is None
+
+
+def test_the_model_hands_its_sample_regime_to_the_hash_backward(monkeypatch):
+    """The hash backward's two path thresholds (few_runs, stage_max) have different optima for a constant step and for steps that grow
+    with the distance (profiles/r05_hash_bwd_thresholds.txt).  They are CALL ARGUMENTS (lse_hash_bwd_opts): the model tells the grid
+    which regime its sampler produces (cone_angle), the grid's meta carries the pair to lse_hash_bwd_ex.  Values do not depend on
+    it (every threshold pair is held against the oracle in test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle)."""
+    import ctypes
+    from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle, _lib, ops
+    seen = []
+    real_call = _lib.call
+
+    def spy(name, *args):
+        if name == "lse_hash_bwd_ex":
+            o = ctypes.cast(args[11], ctypes.POINTER(_lib.HashBwdOpts)).contents
+            seen.append((o.few_runs, o.stage_max))
+        return real_call(name, *args)
+    monkeypatch.setattr(_lib, "call", spy)
+    o, d = random_rays(64, seed=2)
+    for cone, want_dense in ((0.0, True), (0.004, False)):
+        torch.manual_seed(0)
+        m = LSENeRFModel(LSENeRFModelConfig(cone_angle=cone, grid_levels=1, grid_resolution=32, log2_hashmap_size=14),
+                         torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4).cuda().train()
+        m.occupancy_grid.mark_all_occupied()
+        rb = RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(64, 1, dtype=torch.long, device="cuda"))
+        m.exec_get_outputs(rb)["rgb"].sum().backward()
+        assert m.field.mlp_base_grid.dense_steps is want_dense
+        assert m.field.mlp_base_grid.meta.bwd_tuning == (ops.HASH_BWD_DENSE_STEPS if want_dense else ops.HASH_BWD_DEFAULT)
+    assert seen == [(6, 32), (8, 48)], seen

@@ -337,7 +337,7 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "prefetch": {"prefetch": 1}, "prefetch_no_few_runs": {"prefetch": 1, "few_runs": 0}, "prefetch_stage_all": {"prefetch": 1, "stage_max": 64},
                 "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5},
                 # pair-aligned flush lists
-                "few_runs8": {"few_runs": 8},
+                "few_runs8": {"few_runs": 8}, "dense_steps_thresholds": {"few_runs": 6, "stage_max": 32}, "round4_thresholds": {"few_runs": 6, "stage_max": 16},
                 "aligned_pairs": {"gran": 7}, "aligned_pairs_stage_all": {"gran": 7, "stage_max": 64}, "aligned_pairs_probe0": {"gran": 7, "second_probe": 0}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)

@@ -64,7 +64,7 @@ def test_dev_knobs_and_hash_bwd_opts_without_gpu():
     build's knobs are writable inside ``_lib.dev_library()`` only and restored when the block ends."""
     from lsenerf_amd import _lib
     o = _lib.hash_bwd_default_opts()
-    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 6, 3, 32, 0, 16, 0)
+    assert (o.impl, o.gran, o.few_runs, o.second_probe, o.rounds, o.dbg, o.stage_max, o.coarse_levels) == (2, 6, 8, 3, 32, 0, 48, 0)
     assert (o.replicas, o.replica_levels, o.prefetch, o.workspace) == (16, 4, 0, None)
     with _lib.dev_library() as dev:
         assert _lib.get_option("hash_fwd_mapping") == 4 and _lib.get_option("mlp_bwd_cfg") == 28 and _lib.get_option("traverse_vec") == 1
@@ -75,8 +75,8 @@ def test_dev_knobs_and_hash_bwd_opts_without_gpu():
         with pytest.raises(_lib.LseHipError):
             _lib.set_option("no_such_option", 1)
     with _lib.dev_library():
-        assert _lib.get_option("mlp_fwd_cfg") == 28 and _lib.get_option("hash_bwd_few_runs") == 6      # restored on exit
-    assert _lib.hash_bwd_default_opts().few_runs == 6
+        assert _lib.get_option("mlp_fwd_cfg") == 28 and _lib.get_option("hash_bwd_few_runs") == 8      # restored on exit
+    assert _lib.hash_bwd_default_opts().few_runs == 8
     # invalid kernel selections are rejected before anything is launched; development variants are not in the shipped library
     d = _lib.GridDesc()
     d.n_levels, d.n_features = 1, 2

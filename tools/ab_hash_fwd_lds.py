@@ -30,7 +30,10 @@ def timed(fn, iters=9):
     return ts[len(ts) // 2]
 
 
-model, rb, _, jitter = bench.build_workload(dev, 1000)
+model, _sets, _ = bench.build_workload(dev, 1000)      # (one ray set: the round-1..4 fixed draw)
+
+
+rb, _, jitter = _sets[0]
 cfg = model.config
 with torch.no_grad():
     ri, ts_, te_, packed = model.occupancy_grid.sampling(

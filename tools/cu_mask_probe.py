@@ -61,7 +61,8 @@ def timed(fn, stream=None, iters=7):
 
 
 # ---- the headline workload's tensors ---------------------------------------------------------------------------------------
-model, rb, target, jitter = bench.build_workload(dev, 1000)
+model, _sets, _ = bench.build_workload(dev, 1000)      # (one ray set: the round-1..4 fixed draw)
+rb, target, jitter = _sets[0]
 cfg, fld = model.config, model.field
 with torch.no_grad():
     ri, ts_, te_, packed = model.occupancy_grid.sampling(

@@ -5,7 +5,8 @@ import torch
 import bench
 from lsenerf_amd.optim import FlatAdam, FlatParams
 dev = torch.device("cuda", 0)
-model, rb, target, jitter = bench.build_workload(dev, seed=1000)
+model, _sets, _ = bench.build_workload(dev, seed=1000)      # (one ray set: the round-1..4 fixed draw)
+rb, target, jitter = _sets[0]
 flat = FlatParams(model.get_param_groups()["fields"])
 opt = FlatAdam(flat, lr=1e-2, eps=1e-15)
 for _ in range(2):

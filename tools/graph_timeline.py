@@ -13,7 +13,8 @@ if sys.argv[1] == "run_headline":      # the eager M-march step bench.py's `valu
     from lsenerf_amd.optim import FlatAdam, FlatParams
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    model, rb, target, jitter = bench.build_workload(dev, 1000)
+    model, _sets, _ = bench.build_workload(dev, 1000)      # (one ray set: the round-1..4 fixed draw)
+    rb, target, jitter = _sets[0]
     opt = FlatAdam(FlatParams(model.get_param_groups()["fields"]), lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000)
     for _ in range(12):
         bench.train_step(model, rb, target, jitter, opt, 1)

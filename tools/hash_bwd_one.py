@@ -30,7 +30,8 @@ elif regime == "M-packed":
     o, d = bench.sphere_rays(R, torch.Generator().manual_seed(96))
     x01 = fixed(o, d)
 elif regime == "bench":                 # the positions of bench.py's headline step (SURVEY 8d rays, chord inside the box)
-    model, rb, _, jitter = bench.build_workload(dev, 96)
+    model, _sets, _ = bench.build_workload(dev, 96)      # (one ray set: the round-1..4 fixed draw)
+    rb, _, jitter = _sets[0]
     cfg = model.config
     ri, ts, te, packed = model.occupancy_grid.sampling(
         rb.origins.detach(), rb.directions.detach(), near_plane=cfg.near_plane, far_plane=cfg.far_plane,

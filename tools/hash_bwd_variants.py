@@ -42,7 +42,8 @@ def default_config_positions():
                          rs.frustums.ends[..., 0].contiguous(), rs.packed_info, True, None)[0]
 def headline_positions():
     """bench.py's headline step (SURVEY 8d exact: sphere rays, one-level grid fully occupied, step chosen for 1024 samples per ray)."""
-    model, rb, _, jitter = bench.build_workload(dev, 1000)
+    model, _sets, _ = bench.build_workload(dev, 1000)      # (one ray set: the round-1..4 fixed draw)
+    rb, _, jitter = _sets[0]
     cfg = model.config
     with torch.no_grad():
         ri, ts, te, packed = model.occupancy_grid.sampling(
