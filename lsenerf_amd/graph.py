@@ -268,7 +268,7 @@ class GraphedTrainStep:
             self._losses_of.append(self.losses)
             self._outputs_of.append(self.outputs)
             self._ray_grads_of.append(self._collect_ray_grads())
-        self._announced = None       # identity of the rays the other buffer was marched for (see _signature)
+        self._announced = None       # identity of the rays the other buffer was marched for (_signature: holds the tensors)
         self.remarched_unannounced = 0   # calls whose rays were not the announced ones (their samples were marched again)
         self._cur = 0                # the buffer that holds (or will be given) the samples of the rays in the static CURRENT bundles
         self._pm_version = None      # grid_version under which the other buffer was filled by the last replay; None: not filled
@@ -394,7 +394,7 @@ class GraphedTrainStep:
         if self.prefetch:
             # the samples marched ahead belong to the rays that were ANNOUNCED: if the rays given now are not those very tensors,
             # unmodified (same storage, same version counters; jitter likewise), the samples are dropped and these rays marched
-            if self._pm_version is not None and self._announced != self._signature((col, prev, nxt), jitter):
+            if self._pm_version is not None and not self._same_rays(self._announced, self._signature((col, prev, nxt), jitter)):
                 self._pm_version = None
                 self.remarched_unannounced += 1
             return self._replay_prefetch(next_bundles, next_jitter)
@@ -406,14 +406,34 @@ class GraphedTrainStep:
 
     @staticmethod
     def _signature(bundles, jitter):
-        """Identity of a set of rays as cheap as it gets: storage addresses, shapes and in-place version counters."""
+        """Identity of a set of rays: the tensor OBJECTS (held, so that their storage cannot be handed to other rays in between) and
+        their in-place version counters -- origins, directions, nears / fars, times, camera indices, every metadata tensor, the
+        jitter.  Addresses alone are not an identity: a caller that drops the announced bundle and builds a new one commonly gets the
+        same block back from the caching allocator, at version 0."""
         sig = []
         for b in bundles:
-            sig.append(None if b is None else tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (b.origins, b.directions)) +
-                       tuple((k, v.data_ptr(), v._version) for k, v in sorted(b.metadata.items()) if torch.is_tensor(v)) +
-                       tuple((n, getattr(b, n).data_ptr(), getattr(b, n)._version) for n in ("nears", "fars") if getattr(b, n) is not None))
-        sig.append(None if jitter is None else (jitter.data_ptr(), tuple(jitter.shape), jitter._version))
+            if b is None:
+                sig.append(None)
+                continue
+            ts = [b.origins, b.directions] + [getattr(b, n) for n in ("nears", "fars", "times", "camera_indices", "pixel_area")
+                                              if getattr(b, n) is not None] + \
+                 [v for _, v in sorted(b.metadata.items()) if torch.is_tensor(v)]
+            sig.append([(t, t._version) for t in ts])
+        sig.append(None if jitter is None else [(jitter, jitter._version)])
         return sig
+
+    @staticmethod
+    def _same_rays(a, b) -> bool:
+        if a is None or b is None or len(a) != len(b):
+            return False
+        for x, y in zip(a, b):
+            if (x is None) != (y is None):
+                return False
+            if x is None:
+                continue
+            if len(x) != len(y) or any(t1 is not t2 or v1 != v2 for (t1, v1), (t2, v2) in zip(x, y)):
+                return False
+        return True
 
     def _replay_prefetch(self, next_bundles, next_jitter) -> Dict[str, Tensor]:
         est, x = self.model.occupancy_grid, self._cur

@@ -227,6 +227,25 @@ def test_graphed_step_with_the_next_steps_marcher_on_a_side_stream_equals_the_ea
     assert step.remarched_unannounced == 1
     for k in l_e:
         assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (k, l_g[k], l_e[k])
+    # The identity of the announced rays is the tensor OBJECTS + their version counters, and the step HOLDS them until the next call:
+    # a caller that drops the announced bundle cannot get its storage back from the allocator for other rays at the same address and
+    # version 0 (which an address-based signature would take for the announced ones and train on the wrong samples).
+    import gc, weakref
+    bundles, batch, jit = steps[2]
+    ann_bundles, _, ann_jit = batch_of(990)
+    alive = weakref.ref(ann_bundles[0].origins)
+    step(*bundles, batch, jitter=jit, next_bundles=ann_bundles, next_jitter=ann_jit)
+    _eager_step(m_e, o_e, bundles, batch, jit, False)
+    del ann_bundles, ann_jit
+    gc.collect()
+    assert alive() is not None, "the announced tensors must stay alive until the next call has compared them"
+    other, batch, jit = batch_of(991)          # different rays, brand-new objects
+    before = step.remarched_unannounced
+    l_g = {k: float(v) for k, v in step(*other, batch, jitter=jit).items()}
+    l_e, _, _ = _eager_step(m_e, o_e, other, batch, jit, False)
+    assert step.remarched_unannounced == before + 1
+    for k in l_e:
+        assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (k, l_g[k], l_e[k])
     step.check_overflow()
     step.close()
 
