@@ -120,6 +120,43 @@ def test_graphed_step_equals_eager_step(ray_grads):
     assert m_g.deferred_counts is True and m_g.deferred_max_slots == 1 << 24
 
 
+def test_a_replay_survives_eager_passes_with_other_ray_counts_in_between():
+    """A captured step bakes the ADDRESS of GlobalEmbedding's all-zero row-index vector into its row-bias / embedding-gradient
+    kernels and keeps no reference of its own.  Round 4 cached ONE vector per module and replaced it when a training-mode call came
+    with another ray count -- the old one went back to the allocator, and the next replay gathered and scattered embedding rows
+    through whatever was allocated over it.  The vectors are grow-only now and never freed (field.GlobalEmbedding.ray_indices):
+    capture, run eager training-mode passes with fewer AND more rays, poison the allocator with NaN and out-of-range integers,
+    replay, and compare with the eager step."""
+    from lsenerf_amd import RayBundle
+    from lsenerf_amd.field import GlobalEmbedding
+    from lsenerf_amd.graph import GraphedTrainStep
+    (m_e, m_g), (o_e, o_g), batch_of = _setup(False)
+    assert isinstance(m_g.field.embedding_appearance, GlobalEmbedding)
+    b0, batch0, jit0 = batch_of(50)
+    step = GraphedTrainStep(m_g, o_g, *b0, batch0, jitter="input")
+    kept = m_g.field.embedding_appearance.__dict__["_zero_idx"][("cuda", torch.cuda.current_device())]
+    captured_ptr = kept[-1].data_ptr()
+    for n in (77, 3000):             # fewer rays: a prefix of the kept vector; more rays: a NEW, longer vector -- the old one stays
+        o, d = random_rays(n, seed=n)
+        rb = RayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=torch.zeros(n, 1, dtype=torch.long, device="cuda"),
+                       metadata={"appearance_id": torch.zeros(n, dtype=torch.long, device="cuda")})
+        with torch.no_grad():
+            m_g.exec_get_outputs(rb)
+    assert len(kept) == 2 and kept[0].data_ptr() == captured_ptr and kept[1].shape[0] >= 3000
+    junk = [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(16)] + \
+           [torch.full((k,), 0x7FFFFFF0, dtype=torch.int32, device="cuda") for k in (64, 300, 512, 1024, 4096, 1 << 14) for _ in range(8)]
+    del junk
+    for it in range(2):
+        bundles, batch, jit = batch_of(70 + it)
+        l_g = {k: float(v) for k, v in step(*bundles, batch, jitter=jit).items()}
+        l_e, _, _ = _eager_step(m_e, o_e, bundles, batch, jit, False)
+        for k in l_e:
+            assert abs(l_g[k] - l_e[k]) <= 2e-5 * max(1.0, abs(l_e[k])), (it, k, l_g[k], l_e[k])
+    assert bool(torch.isfinite(o_g.flat.data).all()) and int(kept[0].abs().max()) == 0
+    step.check_overflow()
+    step.close()
+
+
 def test_graphed_step_feeds_a_pose_optimiser_outside_the_graph():
     """BASELINE config 4 with the captured step: the spline camera optimiser turns pixel samples into 4 virtual-camera rays per
     pixel OUTSIDE the graph (eager torch code, R:lse_nerf/ns_camera_optimizer.py), the graph renders them, averages the 4 renders
