@@ -215,7 +215,8 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request; 5 = the same with
  *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size);
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
- *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots)
+ *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots);
+ *                     8 (impl 2, development build) = 6 with 320 slots: 52 KB of LDS per workgroup, three workgroups (12 waves) per CU
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 8; 6 is better when
  *                     the step size is constant)
  *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3)

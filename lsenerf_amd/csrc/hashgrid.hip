@@ -798,8 +798,14 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
     constexpr int kEnt = 1 << kEntLog2;        // table entries per cache slot (8 = 64-B line, 4 = 32-B sector)
     constexpr int kPay = 2 * kEnt;             // payload floats per slot = lanes per slot in the flush
     constexpr int kSlotBits = 31 - __builtin_clz((unsigned)kSlots);
+    constexpr bool kPow2 = (kSlots & (kSlots - 1)) == 0;     // 320 slots (three workgroups per CU): multiply-high instead of masks
+    static_assert(kPow2 || (kPair && kFlush2 && kSlots % 64 == 0), "non-power-of-two caches: paired slots, second-generation flush");
     constexpr int kChunk = 64 * kRounds;
     constexpr int kStep = kPair ? 2 : 1;        // second probe: the next slot of the same parity
+    auto wrap = [](uint32_t sl) -> uint32_t {   // sl < 2 * kSlots
+        if constexpr (kPow2) return sl & (uint32_t)(kSlots - 1);
+        else return sl >= (uint32_t)kSlots ? sl - (uint32_t)kSlots : sl;
+    };
     __shared__ uint32_t s_key[4][kSlots];
     __shared__ float s_val[4][kSlots * kPay];
     __shared__ uint16_t s_list[4][kSlots];      // occupied slots
@@ -891,7 +897,10 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                 uint32_t slot[8], old[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if constexpr (kPair)
+                    if constexpr (kPair && !kPow2)      // pair bucket = floor(hash / 2^24 * (kSlots / 2)): the top bits of the product
+                        slot[c] = (((__umul24(gi[c] >> (kEntLog2 + 1), 0x9E3779u) & 0xFFFFFFu) * (uint32_t)(kSlots / 2)) >> 24 << 1) |
+                                  ((gi[c] >> kEntLog2) & 1u);
+                    else if constexpr (kPair)
                         slot[c] = (((__umul24(gi[c] >> (kEntLog2 + 1), 0x9E3779u) >> (25 - kSlotBits)) & (kSlots / 2 - 1)) << 1) |
                                   ((gi[c] >> kEntLog2) & 1u);
                     else
@@ -937,7 +946,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                         const uint32_t hop = (uint32_t)(pr + 1) * kStep;
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            old2[c] = lds_cas(to_mem[c] ? &key[(slot[c] + hop) & (kSlots - 1)] : dummy32, kNoLine,
+                            old2[c] = lds_cas(to_mem[c] ? &key[wrap(slot[c] + hop)] : dummy32, kNoLine,
                                               to_mem[c] ? (gi[c] >> kEntLog2) : kNoLine);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
@@ -947,12 +956,12 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                                 if (cm) {
                                     if (claim)
                                         list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                            (uint16_t)((slot[c] + hop) & (kSlots - 1));
+                                            (uint16_t)wrap(slot[c] + hop);
                                     used += __builtin_popcountll(cm);
                                 }
                             }
                             if (claim || (to_mem[c] && old2[c] == (gi[c] >> kEntLog2))) {
-                                slot[c] = (slot[c] + hop) & (kSlots - 1);
+                                slot[c] = wrap(slot[c] + hop);
                                 okc[c] = true;
                                 to_mem[c] = false;
                             }
@@ -1018,7 +1027,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             constexpr int kPer = 64 / kPay;   // slots per flush instruction
             const int sub = lane & (kPay - 1);
             if constexpr (kFlush2) {
-                static_assert(!kFlush2 || (kPair && kPay == 8 && kSlots == 512), "flush v2: 512 paired 32-byte slots");
+                static_assert(!kFlush2 || (kPair && kPay == 8 && (kSlots == 512 || kSlots == 320)), "flush v2: 512 / 320 paired 32-byte slots");
                 const uint32_t gq = (uint32_t)lane >> 3;
                 touch_next();
                 for (uint32_t t0 = 0; t0 < used; t0 += 32) {
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     lds_u32x4 *k4 = (lds_u32x4 *)key;
                     const u32x4_t none = {kNoLine, kNoLine, kNoLine, kNoLine};
                     k4[lane] = none;
-                    k4[64 + lane] = none;
+                    if (kSlots == 512 || lane < (kSlots - 256) / 4) k4[64 + lane] = none;
                     *dummy32 = kNoLine;      // (the exchange above left 0.f in the idle lanes' dummy word)
                 }
             } else
@@ -1560,7 +1569,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 7, "lse_hash_bwd: opts.gran must be 2 .. 7");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 8, "lse_hash_bwd: opts.gran must be 2 .. 8");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1580,6 +1589,9 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     const float il_scale = o.interleave_from_scale;
     const int rounds = o.rounds, impl = o.impl, dbg = o.dbg;
     (void)rounds;
+#ifndef LSE_DEV_KNOBS
+    (void)dbg;      // (timing ablations exist in the development build only: rejected above)
+#endif
     hipStream_t st = lse::as_stream(stream);
     const float *tb = dx ? table : nullptr;
     // device-side sample count: honoured by the default kernel (and the development build's coarse kernel)
@@ -1657,6 +1669,20 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            return lse::check_launch("lse_hash_bwd");
+        }
+#endif
+#ifdef LSE_DEV_KNOBS
+        // gran 6 with 320 slots: 52 KB of LDS per workgroup -> three workgroups (12 waves) per CU.  Round 5: more waves hide more
+        // latency, fewer slots collide more, and the two cancel where it matters -- headline 2.56 -> 2.58 ms, default configuration
+        // 1.49 -> 1.54, M-packed 3.12 -> 3.23; only the inside-box workload (long runs in the contracted shell, few sectors per
+        // sample) gains, 2.60 -> 2.47 (profiles/r05_hash_bwd_slots320.txt).  The production kernel sits where its CU-side bound
+        // (2 waves per SIMD) and the memory-side request bound (more requests at 3 waves per SIMD) meet.
+        if (o.gran == 8) {
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 320, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 320, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }

@@ -338,6 +338,9 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5},
                 # pair-aligned flush lists
                 "few_runs8": {"few_runs": 8}, "dense_steps_thresholds": {"few_runs": 6, "stage_max": 32}, "round4_thresholds": {"few_runs": 6, "stage_max": 16},
+                # 320 slots (52 KB of LDS per workgroup: three workgroups = 12 waves per CU; non-power-of-two slot arithmetic)
+                "slots320": {"gran": 8}, "slots320_dense_steps": {"gran": 8, "few_runs": 6, "stage_max": 32}, "slots320_probe0": {"gran": 8, "second_probe": 0},
+                "slots320_stage_all_no_few_runs": {"gran": 8, "stage_max": 64, "few_runs": 0}, "slots320_no_replicas": {"gran": 8, "replicas": 0},
                 "aligned_pairs": {"gran": 7}, "aligned_pairs_stage_all": {"gran": 7, "stage_max": 64}, "aligned_pairs_probe0": {"gran": 7, "second_probe": 0}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
@@ -367,7 +370,7 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
         else:
             with pytest.raises(_lib.LseHipError, match="development variant"):
                 _hash_bwd_ex(ops, meta, xg, dy, tg, **kw)
-    assert n_shipped >= 14
+    assert n_shipped >= 16
     assert _lib.dev_available(), "liblse_hip_dev.so is built by __graft_entry__.build() (make -C lsenerf_amd/csrc dev)"
     with _lib.dev_library():
         for name, kw in variants.items():
