@@ -786,11 +786,13 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // kTwo (round 5): the compute half of TWO levels (positions, indices, dy load, table gathers -- then weights, scan, d(x)) is issued
 // before the run ends of either go to the cache: the loads of level l + 1 are in flight under the scan of level l, and two independent
 // instruction streams fill each other's dependency bubbles at two waves per SIMD.  ~50 more live registers (the kernel has 97 to spare).
+// kOneSite (round 5): the cache pass (insert + flush, ~1700 instructions) is inlined at ONE place instead of three (pending queue /
+// unstaged fine level / last flush): the kernel's code shrinks from 39 KB to ~20 KB of the 64 KB instruction cache two CUs share.
 // kAlign (round 3): the two sectors of a line leave as ONE request only when their list entries sit in neighbouring lane groups of the
 // SAME flush instruction; in slot order a sibling pair straddles an 8-entry boundary one time in eight.  With kAlign every occupied
 // pair bucket takes an even-aligned pair of list positions (an absent sibling is an idle entry), so a line is never split.
 template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false,
-          bool kTwo = false>
+          bool kTwo = false, bool kOneSite = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -1376,20 +1378,15 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
-            } else {
+            }
+            {
+                const bool cachey = n_ends > few_runs;      // (wave-uniform) this level's run ends go through the sector cache
                 uint32_t gidx[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gidx[c] = li.offset + idx[c];
-                if (fill + n_ends > 64) {               // the queue cannot take this level: run the pending pass first
-                    insert_pass(lane < fill, q_idx, q_v);
-                    fill = 0;
-                }
-                if (fill == 0 && n_ends > stage_max) {
-                    // fine level: most lanes end a run -- pass straight from the lanes that hold them (no compaction)
-                    insert_pass(run_end && !(dbg & 2), gidx, v);
-                } else {
-                    // append: queue lane fill + r takes the r-th run end of this level (rank -> lane through LDS, then 24
-                    // ds_bpermute moves); the pass runs when the queue is full, at a fine level, or after the last level
+                auto append = [&]() __attribute__((always_inline)) {
+                    // queue lane fill + r takes the r-th run end of this level (rank -> lane through LDS, then 24 ds_bpermute
+                    // moves); the pass runs when the queue is full, at a fine level, or after the last level
                     if (run_end && !(dbg & 2))
                         perm[__builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0))] = (uint32_t)lane;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1409,12 +1406,50 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     }
                     fill += n_ends;
                     __builtin_amdgcn_wave_barrier();
+                };
+                if constexpr (kOneSite) {
+                    // the same decisions through ONE call site of the cache pass: stage 0 = the pending pass (the queue cannot take
+                    // this level), stage 1 = this level unstaged -- or appended to the queue --, stage 2 = the last flush after the
+                    // last level of the range
+                    const bool pend = cachey && fill + n_ends > 64;
+                    const bool direct = cachey && (pend || fill == 0) && n_ends > stage_max;
+                    const bool last = l + 1 == g.l_end;
+#pragma nounroll
+                    for (int stage = pend ? 0 : 1; stage < 3; ++stage) {
+                        if (stage == 1 && !direct) {
+                            if (cachey) append();
+                            continue;
+                        }
+                        if (stage == 2 && !(last && fill > 0)) break;
+                        const bool from_q = stage != 1;
+                        uint32_t gi_[8];
+                        float vv_[16];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) gi_[c] = from_q ? q_idx[c] : gidx[c];
+#pragma unroll
+                        for (int k2 = 0; k2 < 16; ++k2) vv_[k2] = from_q ? q_v[k2] : v[k2];
+                        insert_pass(from_q ? (lane < fill) : (run_end && !(dbg & 2)), gi_, vv_);
+                        if (from_q) fill = 0;
+                    }
+                } else if (cachey) {
+                    if (fill + n_ends > 64) {               // the queue cannot take this level: run the pending pass first
+                        insert_pass(lane < fill, q_idx, q_v);
+                        fill = 0;
+                    }
+                    if (fill == 0 && n_ends > stage_max) {
+                        // fine level: most lanes end a run -- pass straight from the lanes that hold them (no compaction)
+                        insert_pass(run_end && !(dbg & 2), gidx, v);
+                    } else {
+                        append();
+                    }
                 }
             }
         }
     }
     }
-    if (fill > 0) insert_pass(lane < fill, q_idx, q_v);
+    if constexpr (!kOneSite || kTwo) {
+        if (fill > 0) insert_pass(lane < fill, q_idx, q_v);
+    }
     if (WITH_DX) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
@@ -1736,7 +1771,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 9, "lse_hash_bwd: opts.gran must be 2 .. 9");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 10, "lse_hash_bwd: opts.gran must be 2 .. 10");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1846,6 +1881,13 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         // 1.49 -> 1.54, M-packed 3.12 -> 3.23; only the inside-box workload (long runs in the contracted shell, few sectors per
         // sample) gains, 2.60 -> 2.47 (profiles/r05_hash_bwd_slots320.txt).  The production kernel sits where its CU-side bound
         // (2 waves per SIMD) and the memory-side request bound (more requests at 3 waves per SIMD) meet.
+        if (o.gran == 10) {     // gran 6 with ONE inlined copy of the cache pass (kOneSite)
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
+                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
+            return lse::check_launch("lse_hash_bwd");
+        }
         if (o.gran == 9) {      // gran 6 with the compute half of two levels issued together (kTwo)
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
