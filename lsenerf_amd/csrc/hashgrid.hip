@@ -17,7 +17,6 @@
 //     table gradients are f32 global atomics (memory-side on gfx950, so no level/XCD affinity is attempted there).
 #include "common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -783,16 +782,10 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // kPrefetch the loads of level l+1 are issued right after the scan of level l -- BEFORE level l's cache pass -- and are waited for
 // just before the pass sends its first atomic (an empty asm that consumes the registers places the s_waitcnt there): by then they
 // have had the whole insert phase to arrive, and the atomics get the whole next level to retire.
-// kTwo (round 5): the compute half of TWO levels (positions, indices, dy load, table gathers -- then weights, scan, d(x)) is issued
-// before the run ends of either go to the cache: the loads of level l + 1 are in flight under the scan of level l, and two independent
-// instruction streams fill each other's dependency bubbles at two waves per SIMD.  ~50 more live registers (the kernel has 97 to spare).
-// kOneSite (round 5): the cache pass (insert + flush, ~1700 instructions) is inlined at ONE place instead of three (pending queue /
-// unstaged fine level / last flush): the kernel's code shrinks from 39 KB to ~20 KB of the 64 KB instruction cache two CUs share.
 // kAlign (round 3): the two sectors of a line leave as ONE request only when their list entries sit in neighbouring lane groups of the
 // SAME flush instruction; in slot order a sibling pair straddles an 8-entry boundary one time in eight.  With kAlign every occupied
 // pair bucket takes an even-aligned pair of list positions (an absent sibling is an idle entry), so a line is never split.
-template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false,
-          bool kTwo = false, bool kOneSite = false>
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false>
 __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -896,7 +889,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         pending_touch = false;
     };
 
-    auto insert_pass = [&](const bool act, const uint32_t (&gi)[8], const float (&vv)[16]) __attribute__((always_inline)) {
+    auto insert_pass = [&](const bool act, const uint32_t (&gi)[8], const float (&vv)[16]) {
         uint32_t used = 0;   // occupied cache slots (wave-uniform)
             if (__builtin_amdgcn_ballot_w64(act) != 0) {
                 // multiplicative hash of the line id (a slot function linear in the cell coordinates was tried: more
@@ -1095,167 +1088,6 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         __builtin_amdgcn_wave_barrier();
     };
 
-    if constexpr (kTwo) {
-        static_assert(!kTwo || (!kPrefetch && kRounds == 1), "two-level compute: no prefetch variant, one round per wave");
-        // the two levels' state as plain local arrays with COMPILE-TIME slot indices (a struct passed by reference stayed in scratch)
-        LevelInfo t_li[2];
-        float t_w[2][3];
-        uint32_t t_p[2][3];
-        float2 t_gy[2];
-        uint32_t t_idx[2][8];
-        float2 t_tv[2][8];
-        float t_v[2][16];
-        bool t_end[2];
-        using K0 = std::integral_constant<int, 0>;
-        using K1 = std::integral_constant<int, 1>;
-        auto prep = [&](int l, auto KK) __attribute__((always_inline)) {
-            constexpr int K = decltype(KK)::value;      // everything up to the loads (nothing here waits for memory)
-            t_li[K] = level_info(g, l);
-            pos_fract(px[0][0], t_li[K].scale, t_w[K][0], t_p[K][0]);
-            pos_fract(px[0][1], t_li[K].scale, t_w[K][1], t_p[K][1]);
-            pos_fract(px[0][2], t_li[K].scale, t_w[K][2], t_p[K][2]);
-            t_gy[K] = dy[(int64_t)l * n_cap + si[0]];
-            corner_indices(t_li[K], t_p[K][0], t_p[K][1], t_p[K][2], t_idx[K]);
-            if (WITH_DX) {
-                const float2 *__restrict__ tab = table + t_li[K].offset;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) t_tv[K][c] = tab[t_idx[K][c]];
-            }
-        };
-        auto finish = [&](auto KK) __attribute__((always_inline)) {
-            constexpr int K = decltype(KK)::value;           // weights, run scan, d(x)
-            float2 gy = t_gy[K];
-            if (!valid[0]) gy = make_float2(0.f, 0.f);
-            const uint32_t q0 = wave_shr1(t_p[K][0]), q1 = wave_shr1(t_p[K][1]), q2 = wave_shr1(t_p[K][2]);
-            const int head = (lane == 0) || (q0 != t_p[K][0]) || (q1 != t_p[K][1]) || (q2 != t_p[K][2]);
-            const int next_head = wave_shl1(head);
-            t_end[K] = (lane == 63) || next_head;
-            const float w0 = t_w[K][0], w1 = t_w[K][1], w2 = t_w[K][2];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
-                t_v[K][2 * c] = wt * gy.x;
-                t_v[K][2 * c + 1] = wt * gy.y;
-            }
-            if (!(dbg & 4)) {
-                const int row_pos = lane & 15;
-                int flag = head | (row_pos == 0);
-                if (seg_scan_row_step<1>(t_v[K], flag, row_pos) && seg_scan_row_step<2>(t_v[K], flag, row_pos) &&
-                    seg_scan_row_step<4>(t_v[K], flag, row_pos))
-                    seg_scan_row_step<8>(t_v[K], flag, row_pos);
-                int open = !head;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const int o = (off == 1) ? row_shr_i32<1>(open) : (off == 2) ? row_shr_i32<2>(open)
-                                : (off == 4) ? row_shr_i32<4>(open) : row_shr_i32<8>(open);
-                    open &= (row_pos >= off) ? o : 1;
-                }
-                seg_scan_cross_rows(t_v[K], open, lane);
-            }
-            if (WITH_DX) {
-                const float a0 = 1.f - w0, a1 = 1.f - w1, a2 = 1.f - w2;
-                float t[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) t[c] = gy.x * t_tv[K][c].x + gy.y * t_tv[K][c].y;
-                const float d0 = a2 * (a1 * (t[1] - t[0]) + w1 * (t[3] - t[2])) + w2 * (a1 * (t[5] - t[4]) + w1 * (t[7] - t[6]));
-                const float d1 = a2 * (a0 * (t[2] - t[0]) + w0 * (t[3] - t[1])) + w2 * (a0 * (t[6] - t[4]) + w0 * (t[7] - t[5]));
-                const float d2 = a1 * (a0 * (t[4] - t[0]) + w0 * (t[5] - t[1])) + w1 * (a0 * (t[6] - t[2]) + w0 * (t[7] - t[3]));
-                dacc[0][0] = fmaf(t_li[K].scale, d0, dacc[0][0]);
-                dacc[0][1] = fmaf(t_li[K].scale, d1, dacc[0][1]);
-                dacc[0][2] = fmaf(t_li[K].scale, d2, dacc[0][2]);
-            }
-        };
-        auto route = [&](int l, auto KK) __attribute__((always_inline)) {
-            constexpr int K = decltype(KK)::value;     // run ends -> memory (few runs) / queue / cache pass: the same decisions as below
-            const LevelInfo &li = t_li[K];
-            float *__restrict__ dt = (ws != nullptr && l < g.rep_levels)
-                                         ? ws + (size_t)(blockIdx.x & (unsigned)g.rep_mask) * g.rep_stride + 2 * (size_t)li.offset
-                                         : dtable + 2 * (size_t)li.offset;
-            const bool run_end = t_end[K];
-            const uint64_t ends_mask = __builtin_amdgcn_ballot_w64(run_end && !(dbg & 2));
-            const int n_ends = __builtin_popcountll(ends_mask);
-            if (n_ends <= few_runs) {
-                if (n_ends > 0) {
-                    lds_u32 *stage = (lds_u32 *)val;           // [run][8 idx | 16 values]
-                    if (run_end && !(dbg & 2)) {
-                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0));
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) stage[rank * 24 + c] = t_idx[K][c];
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) stage[rank * 24 + 8 + k] = __float_as_uint(t_v[K][k]);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int k16 = lane & 15;
-                    for (int r0 = lane >> 4; r0 < n_ends; r0 += 4) {
-                        const uint32_t e = stage[r0 * 24 + (k16 >> 1)];
-                        const float a = __uint_as_float(stage[r0 * 24 + 8 + k16]);
-                        if (a != 0.f && !(dbg & 16)) atomicAdd(dt + 2 * (size_t)e + (k16 & 1), a);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (int s_ = lane; s_ < n_ends * 24; s_ += 64) stage[s_] = 0u;   // the payload area must read zero again
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
-                uint32_t gidx[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) gidx[c] = li.offset + t_idx[K][c];
-                // the pending pass (the queue cannot take this level) and the unstaged pass of a fine level through ONE call site: the
-                // cache pass is ~1700 instructions and this lambda is instantiated twice
-                const bool pend = fill + n_ends > 64;
-                const bool direct = (pend || fill == 0) && n_ends > stage_max;
-#pragma nounroll
-                for (int it = pend ? 0 : 1; it < (direct ? 2 : 1); ++it) {
-                    const bool from_q = it == 0;
-                    uint32_t gi_[8];
-                    float vv_[16];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) gi_[c] = from_q ? q_idx[c] : gidx[c];
-#pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) vv_[k2] = from_q ? q_v[k2] : t_v[K][k2];
-                    insert_pass(from_q ? (lane < fill) : (run_end && !(dbg & 2)), gi_, vv_);
-                    if (from_q) fill = 0;
-                }
-                if (!direct) {
-                    if (run_end && !(dbg & 2))
-                        perm[__builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0))] = (uint32_t)lane;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int r = lane - fill;
-                    const bool take = r >= 0 && r < n_ends;
-                    const int src = take ? (int)perm[r] : lane;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)gidx[c]);
-                        q_idx[c] = take ? t : q_idx[c];
-                    }
-#pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) {
-                        const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(t_v[K][k2])));
-                        q_v[k2] = take ? t : q_v[k2];
-                    }
-                    fill += n_ends;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        };
-        int l = g.l_begin;
-        for (; l + 1 < g.l_end; l += 2) {
-            prep(l, K0{});
-            prep(l + 1, K1{});
-            finish(K0{});
-            finish(K1{});
-            route(l, K0{});
-            route(l + 1, K1{});
-        }
-        if (l < g.l_end) {
-            prep(l, K0{});
-            finish(K0{});
-            route(l, K0{});
-        }
-    } else {
     if (kPrefetch && g.l_begin < g.l_end) fetch_next(g.l_begin);
     for (int l = g.l_begin; l < g.l_end; ++l) {
         const LevelInfo li = level_info(g, l);
@@ -1378,15 +1210,20 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
-            }
-            {
-                const bool cachey = n_ends > few_runs;      // (wave-uniform) this level's run ends go through the sector cache
+            } else {
                 uint32_t gidx[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gidx[c] = li.offset + idx[c];
-                auto append = [&]() __attribute__((always_inline)) {
-                    // queue lane fill + r takes the r-th run end of this level (rank -> lane through LDS, then 24 ds_bpermute
-                    // moves); the pass runs when the queue is full, at a fine level, or after the last level
+                if (fill + n_ends > 64) {               // the queue cannot take this level: run the pending pass first
+                    insert_pass(lane < fill, q_idx, q_v);
+                    fill = 0;
+                }
+                if (fill == 0 && n_ends > stage_max) {
+                    // fine level: most lanes end a run -- pass straight from the lanes that hold them (no compaction)
+                    insert_pass(run_end && !(dbg & 2), gidx, v);
+                } else {
+                    // append: queue lane fill + r takes the r-th run end of this level (rank -> lane through LDS, then 24
+                    // ds_bpermute moves); the pass runs when the queue is full, at a fine level, or after the last level
                     if (run_end && !(dbg & 2))
                         perm[__builtin_amdgcn_mbcnt_hi((uint32_t)(ends_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends_mask, 0))] = (uint32_t)lane;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1406,50 +1243,11 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     }
                     fill += n_ends;
                     __builtin_amdgcn_wave_barrier();
-                };
-                if constexpr (kOneSite) {
-                    // the same decisions through ONE call site of the cache pass: stage 0 = the pending pass (the queue cannot take
-                    // this level), stage 1 = this level unstaged -- or appended to the queue --, stage 2 = the last flush after the
-                    // last level of the range
-                    const bool pend = cachey && fill + n_ends > 64;
-                    const bool direct = cachey && (pend || fill == 0) && n_ends > stage_max;
-                    const bool last = l + 1 == g.l_end;
-#pragma nounroll
-                    for (int stage = pend ? 0 : 1; stage < 3; ++stage) {
-                        if (stage == 1 && !direct) {
-                            if (cachey) append();
-                            continue;
-                        }
-                        if (stage == 2 && !(last && fill > 0)) break;
-                        const bool from_q = stage != 1;
-                        uint32_t gi_[8];
-                        float vv_[16];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) gi_[c] = from_q ? q_idx[c] : gidx[c];
-#pragma unroll
-                        for (int k2 = 0; k2 < 16; ++k2) vv_[k2] = from_q ? q_v[k2] : v[k2];
-                        insert_pass(from_q ? (lane < fill) : (run_end && !(dbg & 2)), gi_, vv_);
-                        if (from_q) fill = 0;
-                    }
-                } else if (cachey) {
-                    if (fill + n_ends > 64) {               // the queue cannot take this level: run the pending pass first
-                        insert_pass(lane < fill, q_idx, q_v);
-                        fill = 0;
-                    }
-                    if (fill == 0 && n_ends > stage_max) {
-                        // fine level: most lanes end a run -- pass straight from the lanes that hold them (no compaction)
-                        insert_pass(run_end && !(dbg & 2), gidx, v);
-                    } else {
-                        append();
-                    }
                 }
             }
         }
     }
-    }
-    if constexpr (!kOneSite || kTwo) {
-        if (fill > 0) insert_pass(lane < fill, q_idx, q_v);
-    }
+    if (fill > 0) insert_pass(lane < fill, q_idx, q_v);
     if (WITH_DX) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
@@ -1771,7 +1569,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 10, "lse_hash_bwd: opts.gran must be 2 .. 10");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 8, "lse_hash_bwd: opts.gran must be 2 .. 8");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1881,20 +1679,6 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         // 1.49 -> 1.54, M-packed 3.12 -> 3.23; only the inside-box workload (long runs in the contracted shell, few sectors per
         // sample) gains, 2.60 -> 2.47 (profiles/r05_hash_bwd_slots320.txt).  The production kernel sits where its CU-side bound
         // (2 waves per SIMD) and the memory-side request bound (more requests at 3 waves per SIMD) meet.
-        if (o.gran == 10) {     // gran 6 with ONE inlined copy of the cache pass (kOneSite)
-            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            return lse::check_launch("lse_hash_bwd");
-        }
-        if (o.gran == 9) {      // gran 6 with the compute half of two levels issued together (kTwo)
-            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            return lse::check_launch("lse_hash_bwd");
-        }
         if (o.gran == 8) {
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 320, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
                                        tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);

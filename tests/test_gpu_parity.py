@@ -340,10 +340,6 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "few_runs8": {"few_runs": 8}, "dense_steps_thresholds": {"few_runs": 6, "stage_max": 32}, "round4_thresholds": {"few_runs": 6, "stage_max": 16},
                 # 320 slots (52 KB of LDS per workgroup: three workgroups = 12 waves per CU; non-power-of-two slot arithmetic)
                 # the compute half of two levels issued together (development build)
-                # ONE inlined copy of the cache pass (development build)
-                "one_site": {"gran": 10}, "one_site_dense": {"gran": 10, "few_runs": 6, "stage_max": 32}, "one_site_stage_all": {"gran": 10, "stage_max": 64, "few_runs": 0},
-                "one_site_no_stage": {"gran": 10, "stage_max": 0}, "one_site_few16": {"gran": 10, "few_runs": 16},
-                "two_levels": {"gran": 9}, "two_levels_dense": {"gran": 9, "few_runs": 6, "stage_max": 32}, "two_levels_stage_all": {"gran": 9, "stage_max": 64, "few_runs": 0},
                 "slots320": {"gran": 8}, "slots320_dense_steps": {"gran": 8, "few_runs": 6, "stage_max": 32}, "slots320_probe0": {"gran": 8, "second_probe": 0},
                 "slots320_stage_all_no_few_runs": {"gran": 8, "stage_max": 64, "few_runs": 0}, "slots320_no_replicas": {"gran": 8, "replicas": 0},
                 "aligned_pairs": {"gran": 7}, "aligned_pairs_stage_all": {"gran": 7, "stage_max": 64}, "aligned_pairs_probe0": {"gran": 7, "second_probe": 0}}
