@@ -69,6 +69,98 @@ def test_traverse_fma_setup_is_bit_exact_against_the_fma_oracle():
         assert torch.equal(hri.cpu().long(), ri) and torch.equal(hts.cpu(), ts) and torch.equal(hte.cpu(), te), fma
 
 
+def test_estimator_carries_the_traversal_convention_to_both_sampler_paths():
+    """``LSEOccGridEstimator.traverse_fma`` (the attribute that replaced the process-wide option of ABI 4) reaches the synchronising
+    marcher and the count-free (deferred) one: with it, both equal the FMA build of the C oracle bit for bit; without it, the
+    strict build.  A carved 2-level 32^3 grid with cone-angle steps, where the two conventions differ in a handful of intervals."""
+    from oracle import sampling as osamp
+    from lsenerf_amd.grid_estimator import LSEOccGridEstimator
+    g = torch.Generator().manual_seed(11)
+    R = 2048
+    o = torch.randn(R, 3, generator=g)
+    o = 1.5 * o / o.norm(dim=-1, keepdim=True)
+    d = (torch.rand(R, 3, generator=g) - 0.5) - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    b = torch.rand(2, 32, 32, 32, generator=g) < 0.4
+    est = LSEOccGridEstimator([-1.0, -1, -1, 1, 1, 1], resolution=32, levels=2).cuda()
+    est.binaries.copy_(b.cuda())
+    step = 0.005
+    near, far = torch.full((R,), 0.05), torch.full((R,), 1e3)
+    for fma in (False, True):
+        ri, ts, te, packed = osamp.traverse_grids(o, d, b, est.aabbs.cpu(), near, far, step, 0.004, fma=fma)
+        est.traverse_fma = fma
+        h_ri, h_ts, h_te = est.sampling(o.cuda(), d.cuda(), near_plane=0.05, far_plane=1e3, render_step_size=step, cone_angle=0.004,
+                                        stratified=False)
+        assert torch.equal(h_ri.cpu().long(), ri) and torch.equal(h_ts.cpu(), ts) and torch.equal(h_te.cpu(), te), fma
+        res = est.sampling(o.cuda(), d.cuda(), near_plane=0.05, far_plane=1e3, render_step_size=step, cone_angle=0.004,
+                           stratified=False, deferred=True)
+        n = int(res[4])
+        assert n == ri.numel() and torch.equal(res[1][:n].cpu(), ts) and torch.equal(res[2][:n].cpu(), te), fma
+        est.check_deferred_overflow()
+
+
+def test_c_abi_calls_from_concurrent_host_threads_on_their_own_streams():
+    """ABI 5: "no global or thread-local state ... any number of host threads may call concurrently on their own streams".  Four
+    Python threads (ctypes releases the GIL inside every call), each with its own stream, tensors, sizes and device-side count,
+    run hash forward / backward and both fused MLPs for a while; every thread's results equal what the same calls give alone
+    (forward and d(x) bit for bit -- no atomics there --, table gradients to float-atomic noise).  One of the threads also provokes
+    argument errors throughout: the message it reads back is its own (lse_last_error is per thread) and nobody else's calls fail."""
+    import threading
+    from lsenerf_amd import _lib
+    ops = _ops()
+    meta = ops.make_grid_meta(n_levels=8, log2_hashmap_size=15)
+    g = torch.Generator().manual_seed(3)
+    table = ((torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.1).cuda()
+    mm = ops.MlpMeta(32, 64, 1, _lib.LSE_ACT_NONE, _lib.LSE_IN_LEVELMAJOR)
+    params = (torch.randn(mm.n_params, generator=g) * 0.2).cuda()
+    sizes = (7000, 12345, 20011, 4099)
+    xs = [torch.rand(n, 3, generator=g).cuda() for n in sizes]
+    ws = [torch.randn(meta.n_levels, n, 2, generator=g).cuda() for n in sizes]
+    ins = [torch.randn(16, n, 2, generator=g).cuda() for n in sizes]
+    counts = [torch.tensor([n - 17 * (i + 1)], dtype=torch.int64, device="cuda") for i, n in enumerate(sizes)]
+
+    def work(i, n_dev):
+        x = xs[i].clone().requires_grad_(True)
+        t = table.clone().requires_grad_(True)
+        y = ops.hash_encode(x, t, meta, n_dev=n_dev)
+        (y * ws[i]).sum().backward()
+        out = ops.fused_mlp(params, ins[i], mm, sizes[i])
+        return y.detach(), x.grad, t.grad, out.detach()
+
+    alone = [work(i, counts[i]) for i in range(4)]
+    torch.cuda.synchronize()
+    results, errors = [None] * 4, []
+
+    def run(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(12):
+                    r = work(i, counts[i])
+                    if i == 3:      # this thread's own mistakes must stay its own
+                        d = _lib.GridDesc()
+                        d.n_levels, d.n_features = 4, 3
+                        rc = _lib.load().lse_hash_fwd(ctypes.byref(d), None, None, None, 8, None, None)
+                        assert rc == -1 and b"n_features" in _lib.load().lse_last_error()
+                s.synchronize()
+            results[i] = r
+        except Exception as e:      # noqa: BLE001
+            errors.append((i, repr(e)))
+    import ctypes
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        m = int(counts[i])
+        y, dx, dt, out = results[i]
+        y0, dx0, dt0, out0 = alone[i]
+        assert torch.equal(y[:, :m], y0[:, :m]) and torch.equal(dx[:m], dx0[:m]) and torch.equal(out, out0), i
+        assert nmax_err(dt, dt0, 1e-20) < 1e-5, i
+
+
 @pytest.mark.parametrize("levels,res,cone,step", [(1, 32, 0.0, 0.01), (4, 32, 0.004, 0.005), (4, 128, 0.0, 0.0034641)])
 def test_traverse_single_pass_equals_two_pass(levels, res, cone, step):
     """The single-pass marcher (fixed-capacity ray slots + compaction) returns the two-pass result bit for bit; a violated
