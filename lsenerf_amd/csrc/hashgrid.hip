@@ -906,18 +906,25 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     else
                         slot[c] = (__umul24(gi[c] >> kEntLog2, 0x9E3779u) >> (24 - kSlotBits)) & (kSlots - 1);
                 }
+                uint32_t keyc[8];      // the sector a corner belongs to = the cache key
+#pragma unroll
+                for (int c = 0; c < 8; ++c) keyc[c] = gi[c] >> kEntLog2;
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? (gi[c] >> kEntLog2) : kNoLine);
+                    old[c] = lds_cas(act ? &key[slot[c]] : dummy32, kNoLine, act ? keyc[c] : kNoLine);
                 // float LDS atomics run at ~3 cycles per LANE on gfx950 (tools/micro/lds_ops.hip: ds_add_f32 194 cycles
                 // per instruction, ds_cmpst_b64 22): add both features with one 64-bit compare-and-swap
                 lds_u64 *va[8];
-                bool to_mem[8], okc[8];
+                // ONE piece of state per corner: to_mem = "active and not (yet) at home in a slot".  (Until round 5 a second array --
+                // okc -- and exec-masked update blocks carried the same information: ~300 instructions per probe round, half of
+                // them scalar mask bookkeeping; selects on one mask per corner need ~90.)
+                bool to_mem[8];
                 uint64_t cur[8], prev[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const bool claim = act && old[c] == kNoLine;
+                    const bool home = (old[c] == kNoLine) || (old[c] == keyc[c]);      // claimed the slot, or found its own sector there
                     if constexpr (!kPair) {
+                        const bool claim = act && old[c] == kNoLine;
                         const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
                         if (cm) {
                             if (claim)
@@ -926,8 +933,7 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                             used += __builtin_popcountll(cm);
                         }
                     }
-                    okc[c] = claim || (act && old[c] == (gi[c] >> kEntLog2));
-                    to_mem[c] = act && !okc[c];
+                    to_mem[c] = act && !home;
                 }
                 for (int pr = 0; pr < second_probe; ++pr) {
                     // another chance in the next slot for the corners that lost the previous one (batched the same way); a loser keeps
@@ -936,41 +942,40 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     bool any = false;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) any = any || to_mem[c];
-                    // rounds after the first only when at least 8 lanes still hold a loser: a round costs the whole wave ~40 instructions
-                    // whatever the number of losers, and where the kernel is bound by its own instructions (samples in the contracted
-                    // shell: 2.57 -> 2.71 ms with unconditional rounds, 2.66 with the threshold) a handful of direct adds is cheaper;
-                    // the atomic-bound regimes keep their gain (default configuration 1.51 -> 1.48 ms either way)
+                    // rounds after the first only when at least 8 lanes still hold a loser: a round costs the whole wave its
+                    // instructions whatever the number of losers, and where the kernel is bound by its own instructions (samples in
+                    // the contracted shell: 2.57 -> 2.71 ms with unconditional rounds, 2.66 with the threshold) a handful of direct adds
+                    // is cheaper; the atomic-bound regimes keep their gain (default configuration 1.51 -> 1.48 ms either way)
                     const int min_losers = pr == 0 ? 1 : 8;
                     if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(any)) >= min_losers) {
-                        uint32_t old2[8];
+                        uint32_t old2[8], nxt[8];
                         const uint32_t hop = (uint32_t)(pr + 1) * kStep;
 #pragma unroll
+                        for (int c = 0; c < 8; ++c) nxt[c] = wrap(slot[c] + hop);
+#pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            old2[c] = lds_cas(to_mem[c] ? &key[wrap(slot[c] + hop)] : dummy32, kNoLine,
-                                              to_mem[c] ? (gi[c] >> kEntLog2) : kNoLine);
+                            old2[c] = lds_cas(to_mem[c] ? &key[nxt[c]] : dummy32, kNoLine, to_mem[c] ? keyc[c] : kNoLine);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            const bool claim = to_mem[c] && old2[c] == kNoLine;
+                            const bool won = to_mem[c] && ((old2[c] == kNoLine) || (old2[c] == keyc[c]));
                             if constexpr (!kPair) {
+                                const bool claim = to_mem[c] && old2[c] == kNoLine;
                                 const uint64_t cm = __builtin_amdgcn_ballot_w64(claim);
                                 if (cm) {
                                     if (claim)
                                         list[used + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] =
-                                            (uint16_t)wrap(slot[c] + hop);
+                                            (uint16_t)nxt[c];
                                     used += __builtin_popcountll(cm);
                                 }
                             }
-                            if (claim || (to_mem[c] && old2[c] == (gi[c] >> kEntLog2))) {
-                                slot[c] = wrap(slot[c] + hop);
-                                okc[c] = true;
-                                to_mem[c] = false;
-                            }
+                            slot[c] = won ? nxt[c] : slot[c];
+                            to_mem[c] = to_mem[c] && !won;
                         }
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    va[c] = okc[c] ? (lds_u64 *)&val[slot[c] * kPay + (gi[c] & (kEnt - 1)) * 2] : dummy64;
+                    va[c] = (act && !to_mem[c]) ? (lds_u64 *)&val[slot[c] * kPay + (gi[c] & (kEnt - 1)) * 2] : dummy64;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) cur[c] = *va[c];
 #pragma unroll
