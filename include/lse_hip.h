@@ -216,7 +216,10 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     256 slots (three workgroups per CU: faster cache passes, more collision requests -- equal at the metric size);
  *                     6 (impl 2, default) = 4 with the second-generation flush (list stored trip-major transposed, payload read and
  *                     zeroed by one LDS exchange, keys reset in bulk: 9 instead of 20 LDS instructions per 32 flushed slots);
- *                     8 (impl 2, development build) = 6 with 320 slots: 52 KB of LDS per workgroup, three workgroups (12 waves) per CU
+ *                     -- in workgroups of ONE wave since round 5 (a workgroup's LDS is released when its last wave retires);
+ *                     development build only: 8 = 6 with 320 slots in workgroups of four waves (12 waves per CU), 9 / 11 = 384
+ *                     slots in workgroups of two / one waves (10 / 9 waves per CU), 10 = 448 slots, one wave (9 waves per CU),
+ *                     12 / 13 = 512 slots in workgroups of four (the shape until round 5) / two waves
  *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 8; 6 is better when
  *                     the step size is constant)
  *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3)
@@ -229,7 +232,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                 the coarsest levels are a few thousand 64-byte lines that EVERY wave of a launch adds to, and the memory-side
  *                 atomic units serialise requests to one line: the direct adds (few_runs path, coarse kernel) of the levels below
  *                 replica_levels (default 4: 1 MB of table) go to one of `replicas` (default 16, a power of two) zero-initialised copies
- *                 in `workspace`, chosen by the workgroup index, and a small kernel folds them into dtable at the end of the call
+ *                 in `workspace`, chosen by the index of the wave's group of four, and a small kernel folds them into dtable at the end of the call
  *                 (leaving the workspace zero).  workspace == NULL (lse_hash_bwd, lse_hash_bwd_levels): no replicas, same values
  *   dbg           timing experiments only (bit 0: skip flush atomics, bit 1: skip run ends, bit 2: skip the scan) -> WRONG results
  * lse_hash_bwd / lse_hash_bwd_levels use lse_hash_bwd_default_opts(). */

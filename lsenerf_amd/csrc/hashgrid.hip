@@ -785,8 +785,11 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // kAlign (round 3): the two sectors of a line leave as ONE request only when their list entries sit in neighbouring lane groups of the
 // SAME flush instruction; in slot order a sibling pair straddles an 8-entry boundary one time in eight.  With kAlign every occupied
 // pair bucket takes an even-aligned pair of list positions (an absent sibling is an idle entry), so a line is never split.
-template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false>
-__global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
+// kWaves: waves per workgroup.  Nothing below synchronises across waves (every wave owns its cache), so the workgroup size only sets
+// the granularity at which LDS is handed out: 4 x 512 slots = 80 KB -> 8 waves per CU; 2 x 384 slots = 30.5 KB -> 10 waves per CU.
+template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false,
+          int kWaves = 4>
+__global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
                                                               float *__restrict__ dtable, float *__restrict__ dx,
@@ -806,19 +809,22 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         if constexpr (kPow2) return sl & (uint32_t)(kSlots - 1);
         else return sl >= (uint32_t)kSlots ? sl - (uint32_t)kSlots : sl;
     };
-    __shared__ uint32_t s_key[4][kSlots];
-    __shared__ float s_val[4][kSlots * kPay];
-    __shared__ uint16_t s_list[4][kSlots];      // occupied slots
-    __shared__ uint32_t s_dummy32[4][64];
-    __shared__ uint64_t s_dummy64[4][64];
-    __shared__ uint32_t s_perm[4][64];          // rank -> lane of the run ends being staged
+    __shared__ uint32_t s_key[kWaves][kSlots];
+    __shared__ float s_val[kWaves][kSlots * kPay];
+    __shared__ uint16_t s_list[kWaves][kSlots];      // occupied slots
+    // LDS is handed out in 1280-byte portions: 448 slots fit nine times into a CU only when the idle lanes' 32-bit dummy word is the
+    // low half of their 64-bit one (either holds don't-care values between uses: every use overwrites or ignores it)
+    constexpr bool kTightLds = kSlots == 448;
+    __shared__ uint32_t s_dummy32[kTightLds ? 1 : kWaves][64];
+    __shared__ uint64_t s_dummy64[kWaves][64];
+    __shared__ uint32_t s_perm[kWaves][64];          // rank -> lane of the run ends being staged
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * kChunk;
+    const int64_t wave_base = ((int64_t)blockIdx.x * kWaves + wave) * kChunk;
     if (wave_base >= n) return;
     lds_u32 *key = (lds_u32 *)&s_key[wave][0];
     lds_f32 *val = (lds_f32 *)&s_val[wave][0];
     lds_u16 *list = (lds_u16 *)&s_list[wave][0];
-    lds_u32 *dummy32 = (lds_u32 *)&s_dummy32[wave][lane];
+    lds_u32 *dummy32 = kTightLds ? (lds_u32 *)&s_dummy64[wave][lane] : (lds_u32 *)&s_dummy32[wave][lane];
     lds_u64 *dummy64 = (lds_u64 *)&s_dummy64[wave][lane];
     lds_u32 *perm = (lds_u32 *)&s_perm[wave][0];
     *dummy32 = kNoLine;
@@ -974,8 +980,13 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    va[c] = (act && !to_mem[c]) ? (lds_u64 *)&val[slot[c] * kPay + (gi[c] & (kEnt - 1)) * 2] : dummy64;
+                for (int c = 0; c < 8; ++c) {
+                    // address for every lane, then ONE select (left to itself the compiler guards each address with its own
+                    // exec-masked block: 29 s_and_saveexec + 17 branches for the eight corners)
+                    uint32_t home_p = (uint32_t)(uintptr_t)(lds_u64 *)&val[slot[c] * kPay + (gi[c] & (kEnt - 1)) * 2];
+                    asm volatile("" : "+v"(home_p));
+                    va[c] = (act && !to_mem[c]) ? (lds_u64 *)(uintptr_t)home_p : dummy64;
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) cur[c] = *va[c];
 #pragma unroll
@@ -1032,7 +1043,8 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
             constexpr int kPer = 64 / kPay;   // slots per flush instruction
             const int sub = lane & (kPay - 1);
             if constexpr (kFlush2) {
-                static_assert(!kFlush2 || (kPair && kPay == 8 && (kSlots == 512 || kSlots == 320)), "flush v2: 512 / 320 paired 32-byte slots");
+                static_assert(!kFlush2 || (kPair && kPay == 8 && kSlots >= 256 && kSlots <= 512 && kSlots % 64 == 0),
+                              "flush v2: 256 .. 512 paired 32-byte slots (bulk key reset: 8 keys per lane)");
                 const uint32_t gq = (uint32_t)lane >> 3;
                 touch_next();
                 for (uint32_t t0 = 0; t0 < used; t0 += 32) {
@@ -1098,10 +1110,10 @@ __global__ __launch_bounds__(256) void hash_bwd_batched_kernel(GridParams g, con
         const LevelInfo li = level_info(g, l);
         // (few-runs path only)  The coarsest levels are a few thousand lines that every wave of the launch adds to: the
         // memory-side units serialise same-line requests (M-packed: 5 % of the kernel's requests, 0.6 of its 3.6 ms), so
-        // those adds go to one of several replicas of the level, picked by the workgroup index, and
+        // those adds go to one of several replicas of the level, picked by the index of the wave's group of four, and
         // hash_bwd_reduce_replicas_kernel folds the replicas into the table gradient afterwards
         float *__restrict__ dt = (ws != nullptr && l < g.rep_levels)
-                                     ? ws + (size_t)(blockIdx.x & (unsigned)g.rep_mask) * g.rep_stride + 2 * (size_t)li.offset
+                                     ? ws + (size_t)((blockIdx.x * kWaves / 4) & (unsigned)g.rep_mask) * g.rep_stride + 2 * (size_t)li.offset
                                      : dtable + 2 * (size_t)li.offset;
         const float2 *__restrict__ tab = table + li.offset;
 #pragma unroll
@@ -1574,7 +1586,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 8, "lse_hash_bwd: opts.gran must be 2 .. 8");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 13, "lse_hash_bwd: opts.gran must be 2 .. 13");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1655,6 +1667,19 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
+        // (workgroups of WAVES waves with SLOTS cache slots per wave; nothing in the kernel synchronises across waves)
+#define LSE_HASH_BWD_LAUNCH(SLOTS, WAVES)                                                                                              \
+        {                                                                                                                                 \
+            const int64_t bl = (n + (WAVES) * 64 - 1) / ((WAVES) * 64);                                                                   \
+            LSE_REQUIRE(bl < (1ll << 31), "lse_hash_bwd: grid too large");                                                                \
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, SLOTS, 2, true, true, false, false, WAVES>), dim3((unsigned)bl),    \
+                                       dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe,       \
+                                       o.stage_max, ws, n_dev);                                                                          \
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, SLOTS, 2, true, true, false, false, WAVES>), dim3((unsigned)bl),      \
+                                    dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe,          \
+                                    o.stage_max, ws, n_dev);                                                                             \
+            return lse::check_launch("lse_hash_bwd");                                                                                     \
+        }
 #ifdef LSE_DEV_KNOBS
         if (o.gran == 5) {      // the same with 256 slots: half the LDS, three workgroups per CU
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 256, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
@@ -1691,14 +1716,21 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
                                     tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
             return lse::check_launch("lse_hash_bwd");
         }
+        // between the two: smaller workgroups hand the LDS out in finer portions.  gran 9: 384 slots, two waves per workgroup (30.5 KB)
+        // -> 10 waves per CU; gran 10: 448 slots, one wave per workgroup (17.6 KB) -> 9 waves per CU; gran 11: 384 slots, one wave; gran 12 / 13: 512 slots in workgroups of four (the shape until round 5) / two waves.
+        if (o.gran == 9) LSE_HASH_BWD_LAUNCH(384, 2)
+        if (o.gran == 10) LSE_HASH_BWD_LAUNCH(448, 1)
+        if (o.gran == 11) LSE_HASH_BWD_LAUNCH(384, 1)
+        if (o.gran == 12) LSE_HASH_BWD_LAUNCH(512, 4)
+        if (o.gran == 13) LSE_HASH_BWD_LAUNCH(512, 2)
 #endif
-        if (o.gran == 6) {      // gran 4 with the second-generation flush (fewer DS instructions per cache pass)
-            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                       tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, 512, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,
-                                    tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe, o.stage_max, ws, n_dev);
-            return lse::check_launch("lse_hash_bwd");
-        }
+        // THE production kernel: paired 32-byte sectors, second-generation flush, 512 slots per wave, ONE wave per workgroup.  A
+        // workgroup's LDS is released when its last wave retires, and waves differ in how many cache passes their samples need:
+        // in workgroups of four (until round 5) a CU held 20 KB per early finisher idle.  One wave per workgroup: samples in the
+        // contracted shell 2.53 -> 2.40 ms, headline, M-packed and the default configuration within +-1 %
+        // (profiles/r05_hash_bwd_workgroup_size.txt).
+        if (o.gran == 6) LSE_HASH_BWD_LAUNCH(512, 1)
+#undef LSE_HASH_BWD_LAUNCH
 #ifdef LSE_DEV_KNOBS
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, 512, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, x01, dy2,

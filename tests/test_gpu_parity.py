@@ -434,6 +434,10 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 # the compute half of two levels issued together (development build)
                 "slots320": {"gran": 8}, "slots320_dense_steps": {"gran": 8, "few_runs": 6, "stage_max": 32}, "slots320_probe0": {"gran": 8, "second_probe": 0},
                 "slots320_stage_all_no_few_runs": {"gran": 8, "stage_max": 64, "few_runs": 0}, "slots320_no_replicas": {"gran": 8, "replicas": 0},
+                # the workgroup size sets the portions LDS is handed out in (production: 512 slots, ONE wave per workgroup):
+                # 384 slots x 2 waves (10 waves per CU), 448 x 1 (9), 384 x 1, 512 x 4 (the shape until round 5), 512 x 2
+                "slots384_wg2": {"gran": 9}, "slots384_wg2_dense_steps": {"gran": 9, "few_runs": 6, "stage_max": 32}, "slots384_wg2_stage_all_no_few_runs": {"gran": 9, "stage_max": 64, "few_runs": 0},
+                "slots448_wg1": {"gran": 10}, "slots448_wg1_probe0_stage_all": {"gran": 10, "second_probe": 0, "stage_max": 64}, "slots384_wg1": {"gran": 11}, "slots512_wg4": {"gran": 12}, "slots512_wg4_dense_steps": {"gran": 12, "few_runs": 6, "stage_max": 32}, "slots512_wg2": {"gran": 13},
                 "aligned_pairs": {"gran": 7}, "aligned_pairs_stage_all": {"gran": 7, "stage_max": 64}, "aligned_pairs_probe0": {"gran": 7, "second_probe": 0}}
     # floor() decisions of samples that sit within rounding of a cell face may differ between the two position formulas
     on_face = torch.zeros(N, dtype=torch.bool)
