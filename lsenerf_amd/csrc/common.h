@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <algorithm>
+#include <atomic>
 #include "../../include/lse_hip.h"
 
 namespace lse {
@@ -22,6 +23,24 @@ static inline int check_launch(const char *what)
         set_error("%s: %s", what, hipGetErrorString(e));
         return LSE_E_LAUNCH;
     }
+    return LSE_OK;
+}
+
+// More than 64 KB of dynamic LDS has to be allowed per kernel AND per device.  `done` (one static per kernel instantiation) remembers
+// the devices of this process that have it: a cache of an idempotent driver setting, safe from any thread, and a host that drives
+// several GPUs from one process gets the attribute on each of them.
+static inline int allow_dynamic_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done, const char *what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return LSE_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: cannot raise dynamic LDS to %d bytes: %s", what, bytes, hipGetErrorString(e));
+        return LSE_E_LAUNCH;
+    }
+    done.fetch_or(bit, std::memory_order_release);
     return LSE_OK;
 }
 

@@ -1460,16 +1460,11 @@ int launch_bwd_cfg(const MlpArgs &a, hipStream_t st)
         const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);
         const size_t lds_bytes = imgs * 256 + (size_t)(NW * kTrWave) * sizeof(float);
         (void)n_params;
-        static bool attr_set = false;   // per instantiation: allow more than the default 64 KiB of dynamic LDS
-        if (!attr_set && lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&mlp_bwd_kernel<KIN, WIDTH, NHL, INL, true, CT, NW>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) {
-                lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds_bytes, hipGetErrorString(e));
-                return LSE_E_LAUNCH;
-            }
-            attr_set = true;
+        static std::atomic<uint64_t> lds_allowed{0};   // per instantiation: devices that allow more than the default 64 KiB of dynamic LDS
+        if (lds_bytes > 64 * 1024) {
+            const int rc_lds = lse::allow_dynamic_lds(reinterpret_cast<const void *>(&mlp_bwd_kernel<KIN, WIDTH, NHL, INL, true, CT, NW>), (int)lds_bytes, lds_allowed,
+                                                      "lse_mlp_bwd");
+            if (rc_lds) return rc_lds;
         }
         hipLaunchKernelGGL((mlp_bwd_kernel<KIN, WIDTH, NHL, INL, true, CT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
     } else {
@@ -1487,15 +1482,10 @@ int launch_bwd2(const MlpArgs &a, hipStream_t st)
     const int64_t tiles = (a.n + 31) / 32;
     const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);     // one resident workgroup per CU
     const size_t lds_bytes = imgs * 256 + (size_t)(NW * kTrWave) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES, RECOMP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) {
-            lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds_bytes, hipGetErrorString(e));
-            return LSE_E_LAUNCH;
-        }
-        attr_set = true;
+    static std::atomic<uint64_t> lds_allowed{0};
+    if (lds_bytes > 64 * 1024) {
+        const int rc_lds = lse::allow_dynamic_lds(reinterpret_cast<const void *>(&mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES, RECOMP>), (int)lds_bytes, lds_allowed, "lse_mlp_bwd");
+        if (rc_lds) return rc_lds;
     }
     hipLaunchKernelGGL((mlp_bwd2_kernel<KIN, WIDTH, NHL, INL, BIAS_ONES, RECOMP>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
     return lse::check_launch("lse_mlp_bwd");
@@ -1508,16 +1498,9 @@ int launch_bwd3_cfg(const MlpArgs &a, hipStream_t st)
     static_assert(lds_bytes <= 160 * 1024, "LDS budget of one CU");
     const int64_t tiles = (a.n + 16 * CT - 1) / (16 * CT);
     const int blocks = (int)std::min<int64_t>((tiles + NW - 1) / NW, 256);     // one resident workgroup per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES, CT, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) {
-            lse::set_error("lse_mlp_bwd: cannot raise dynamic LDS to %d bytes: %s", lds_bytes, hipGetErrorString(e));
-            return LSE_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_allowed{0};      // (per instantiation) devices of this process that allow lds_bytes of dynamic LDS
+    const int rc_lds = lse::allow_dynamic_lds(reinterpret_cast<const void *>(&mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES, CT, NW>), lds_bytes, lds_allowed, "lse_mlp_bwd");
+    if (rc_lds) return rc_lds;
     hipLaunchKernelGGL((mlp_bwd3_kernel<KIN, NHL, INL, BIAS, BIAS_ONES, CT, NW>), dim3(blocks), dim3(64 * NW), lds_bytes, st, a);
     return lse::check_launch("lse_mlp_bwd");
 }
