@@ -25,8 +25,14 @@ from .rays import Frustums, RaySamples
 
 
 class FieldHeadNames(Enum):
+    """nerfstudio ``FieldHeadNames`` (the members a nerfacto-style field can return)."""
     RGB = "rgb"
     DENSITY = "density"
+    PRED_NORMALS = "pred_normals"
+    UNCERTAINTY = "uncertainty"
+    TRANSIENT_RGB = "transient_rgb"
+    TRANSIENT_DENSITY = "transient_density"
+    SEMANTICS = "semantics"
 
 
 def _pad16(n: int) -> int:
@@ -140,6 +146,85 @@ class MLP(nn.Module):
                 x = torch.cat([x, torch.ones(n, self.in_pad - x.shape[-1], device=x.device, dtype=x.dtype)], dim=-1)
             out = ops.fused_mlp(self.params, x.contiguous(), self.meta(), n)
         return out[:, : self.out_dim].view(*in_tensor.shape[:-1], self.out_dim)
+
+
+class DenseMLP(nn.Module):
+    """nerfstudio ``MLP(implementation="tcnn")`` for the shapes the fused kernels do not cover (outputs wider than 16): the side
+    heads the reference's field can switch on (R:lse_nerf/lse_field.py:210-252).  Same flat ``params`` as tcnn (bias-free,
+    row-major ``[out, in]`` per layer, input padded to a multiple of 16 with ones, output to a multiple of 16), evaluated with
+    the device's library GEMMs (rocBLAS behind ``torch.mm``) in fp32 -- plain GEMMs off the hot path, differentiated by autograd."""
+
+    def __init__(self, in_dim: int, num_layers: int, layer_width: int, out_dim: int, activation=None, out_activation=None,
+                 implementation: str = "hip") -> None:
+        super().__init__()
+        assert out_activation is None, "the side heads end in a linear layer"
+        self.in_dim, self.out_dim, self.layer_width, self.num_layers = in_dim, out_dim, layer_width, num_layers
+        self.in_pad, self.out_pad = _pad16(in_dim), _pad16(out_dim)
+        self.shapes = [(layer_width, self.in_pad)] + [(layer_width, layer_width)] * (num_layers - 2) + [(self.out_pad, layer_width)]
+        chunks = []
+        for (o, i) in self.shapes:   # tcnn xavier_uniform
+            b = math.sqrt(6.0 / (i + o))
+            chunks.append((torch.rand(o * i) * 2 - 1) * b)
+        self.params = nn.Parameter(torch.cat(chunks))
+
+    def get_out_dim(self) -> int:
+        return self.out_dim
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        x = in_tensor.reshape(-1, in_tensor.shape[-1])
+        if x.shape[-1] < self.in_pad:
+            x = torch.cat([x, torch.ones(x.shape[0], self.in_pad - x.shape[-1], device=x.device, dtype=x.dtype)], dim=-1)
+        off = 0
+        for k, (o, i) in enumerate(self.shapes):
+            w = self.params[off:off + o * i].view(o, i)
+            off += o * i
+            x = x @ w.t()
+            if k < len(self.shapes) - 1:
+                x = torch.relu(x)
+        return x[:, : self.out_dim].reshape(*in_tensor.shape[:-1], self.out_dim)
+
+
+class FieldHead(nn.Module):
+    """nerfstudio ``FieldHead``: ``net = nn.Linear(in_dim, out_dim)`` + activation (state-dict key ``<name>.net.*``)."""
+
+    def __init__(self, out_dim: int, field_head_name: FieldHeadNames, in_dim: int, activation: Optional[nn.Module] = None) -> None:
+        super().__init__()
+        self.out_dim, self.field_head_name, self.in_dim, self.activation = out_dim, field_head_name, in_dim, activation
+        self.net = nn.Linear(in_dim, out_dim)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        out = self.net(in_tensor)
+        return out if self.activation is None else self.activation(out)
+
+
+class PredNormalsFieldHead(FieldHead):
+    """nerfstudio ``PredNormalsFieldHead``: tanh, then unit length."""
+
+    def __init__(self, in_dim: int) -> None:
+        super().__init__(3, FieldHeadNames.PRED_NORMALS, in_dim, nn.Tanh())
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return torch.nn.functional.normalize(super().forward(in_tensor), dim=-1)
+
+
+class FrequencyEncoding(nn.Module):
+    """nerfstudio ``NeRFEncoding(in_dim, num_frequencies, min_freq_exp=0, max_freq_exp=num_frequencies-1, implementation="tcnn")``
+    = tcnn's ``Frequency`` encoding (R:lse_nerf/lse_field.py:190-192): output ``j`` of input ``i`` is
+    ``sin(x_i * 2^((j / 2) % F) * pi + (j % 2) * pi / 2)`` -- per input dimension (sin, cos) of frequency 0, (sin, cos) of
+    frequency 1, ...; parameter-free, element-wise torch ops on the device."""
+
+    def __init__(self, in_dim: int = 3, num_frequencies: int = 2) -> None:
+        super().__init__()
+        self.in_dim, self.num_frequencies = in_dim, num_frequencies
+
+    def get_out_dim(self) -> int:
+        return self.in_dim * self.num_frequencies * 2
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        f = torch.exp2(torch.arange(self.num_frequencies, device=in_tensor.device, dtype=in_tensor.dtype)) * math.pi
+        arg = in_tensor[..., :, None, None] * f[:, None]                                             # [.., in, F, 1]
+        arg = arg + torch.tensor([0.0, math.pi / 2], device=in_tensor.device, dtype=in_tensor.dtype)  # [.., in, F, 2]
+        return torch.sin(arg).reshape(*in_tensor.shape[:-1], self.get_out_dim())
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -272,7 +357,9 @@ class LSEField(nn.Module):
     builds), the string ``"inf"``, or ``None`` (aabb normalisation).  ``implementation``: ``"tcnn"`` (the reference's
     value, R:lse_nerf/lsenerf.py:175) and ``"hip"`` both select the gfx950 kernels with tcnn's parameter layouts and
     numerics; ``"torch"`` (nerfstudio's CPU fallback with different layouts) is the oracle's domain and raises.  The heads
-    the reference leaves switched off (transient / semantics / predicted normals) raise only when switched on."""
+    the reference's model leaves switched off (transient / semantics / predicted normals, R:lse_nerf/lsenerf.py:168-176) are
+    served by ``get_outputs`` / ``forward`` like the reference's (R:lse_nerf/lse_field.py:313-345): tcnn-layout MLPs on the
+    device's library GEMMs, off the fused render path, which returns RGB and density only."""
 
     def __init__(self, aabb: Tensor, num_images: int, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15,
                  num_levels: int = 16, base_res: int = 16, max_res: int = 2048, log2_hashmap_size: int = 19,
@@ -287,11 +374,6 @@ class LSEField(nn.Module):
         if implementation not in ("tcnn", "hip"):
             raise NotImplementedError(f"implementation='{implementation}': this field runs the gfx950 kernels with tcnn "
                                       "semantics ('tcnn' / 'hip'); nerfstudio's torch fallback is restated in oracle/ only")
-        for flag, name in ((use_transient_embedding, "use_transient_embedding"), (use_semantics, "use_semantics"),
-                           (use_pred_normals, "use_pred_normals")):
-            if flag:
-                raise NotImplementedError(f"{name}=True: head not on the LSENeRF path (R:lse_nerf/lsenerf.py:168-176 leaves "
-                                          "it off); not implemented")
         assert geo_feat_dim == 15, "the fused head kernel assumes 1 + 15 base outputs"
         self.register_buffer("aabb", aabb.float())
         self.geo_feat_dim = geo_feat_dim
@@ -305,7 +387,8 @@ class LSEField(nn.Module):
         self.average_init_density = average_init_density
         self.appearance_embedding_dim = appearance_embedding_dim
         self.use_average_appearance_embedding = use_average_appearance_embedding
-        self.use_transient_embedding, self.use_semantics, self.use_pred_normals = False, False, False
+        self.use_transient_embedding, self.use_semantics, self.use_pred_normals = \
+            bool(use_transient_embedding), bool(use_semantics), bool(use_pred_normals)
         self.pass_semantic_gradients = pass_semantic_gradients
         self.base_res = base_res
         self.step = 0
@@ -325,6 +408,23 @@ class LSEField(nn.Module):
                                 out_dim=1 + geo_feat_dim, out_activation=None, in_layout=_lib.LSE_IN_LEVELMAJOR)
         self.mlp_head = MLP(in_dim=16 + geo_feat_dim + self.appearance_embedding_dim, num_layers=num_layers_color,
                             layer_width=hidden_dim_color, out_dim=3, out_activation="Sigmoid")
+        # side heads (R:lse_nerf/lse_field.py:190-252; off in every LSENeRF preset): same modules, names and parameter layouts
+        self.position_encoding = FrequencyEncoding(in_dim=3, num_frequencies=2)
+        if self.use_transient_embedding:
+            self.transient_embedding_dim = transient_embedding_dim
+            self.embedding_transient = Embedding(num_images, transient_embedding_dim)
+            self.mlp_transient = DenseMLP(in_dim=geo_feat_dim + transient_embedding_dim, num_layers=num_layers_transient,
+                                          layer_width=hidden_dim_transient, out_dim=hidden_dim_transient)
+            self.field_head_transient_uncertainty = FieldHead(1, FieldHeadNames.UNCERTAINTY, hidden_dim_transient, nn.Softplus())
+            self.field_head_transient_rgb = FieldHead(3, FieldHeadNames.TRANSIENT_RGB, hidden_dim_transient, nn.Sigmoid())
+            self.field_head_transient_density = FieldHead(1, FieldHeadNames.TRANSIENT_DENSITY, hidden_dim_transient, nn.Softplus())
+        if self.use_semantics:
+            self.mlp_semantics = DenseMLP(in_dim=geo_feat_dim, num_layers=2, layer_width=64, out_dim=hidden_dim_transient)
+            self.field_head_semantics = FieldHead(num_semantic_classes, FieldHeadNames.SEMANTICS, hidden_dim_transient, None)
+        if self.use_pred_normals:
+            self.mlp_pred_normals = DenseMLP(in_dim=geo_feat_dim + self.position_encoding.get_out_dim(), num_layers=3,
+                                             layer_width=64, out_dim=hidden_dim_transient)
+            self.field_head_pred_normals = PredNormalsFieldHead(in_dim=hidden_dim_transient)
         self._aabb6 = None
         self.reuse_prepass = True  # the main pass re-uses the visibility pre-pass's positions / hash features of the survivors
         self._prepass = None
@@ -525,9 +625,37 @@ class LSEField(nn.Module):
             eidx = self.embedding_appearance.ray_indices(meta, cams, n_rays, dev).contiguous()
         else:
             table, eidx = self._eval_emb(n_rays, dev)
+        outputs = self._side_heads(ray_samples, density_embedding, n, ridx)
         out16 = self.rgb_packed(h, dirs, eidx, ridx, pinfo, table)
         rgb = out16[:, :3].view(*fr.directions.shape[:-1], 3)
-        return {FieldHeadNames.RGB: rgb}
+        outputs[FieldHeadNames.RGB] = rgb
+        return outputs
+
+    def _side_heads(self, ray_samples, density_embedding: Tensor, n: int, ridx: Optional[Tensor]) -> Dict[FieldHeadNames, Tensor]:
+        """R:lse_nerf/lse_field.py:313-345: transient (training only), semantics and predicted-normal outputs of the heads that
+        are switched on; ``{}`` for the LSENeRF presets."""
+        outputs: Dict[FieldHeadNames, Tensor] = {}
+        if not (self.use_transient_embedding or self.use_semantics or self.use_pred_normals):
+            return outputs
+        fr = ray_samples.frustums
+        shape = fr.directions.shape[:-1]
+        geo = density_embedding.reshape(n, self.geo_feat_dim)
+        if self.use_transient_embedding and self.training:
+            cams = ray_samples.camera_indices.reshape(-1).long()
+            if cams.shape[0] != n:        # packed samples carry one camera index per RAY
+                cams = cams[ridx.long()]
+            x = self.mlp_transient(torch.cat([geo, self.embedding_transient(cams)], dim=-1)).view(*shape, -1)
+            outputs[FieldHeadNames.UNCERTAINTY] = self.field_head_transient_uncertainty(x)
+            outputs[FieldHeadNames.TRANSIENT_RGB] = self.field_head_transient_rgb(x)
+            outputs[FieldHeadNames.TRANSIENT_DENSITY] = self.field_head_transient_density(x)
+        if self.use_semantics:
+            x = self.mlp_semantics(geo if self.pass_semantic_gradients else geo.detach()).view(*shape, -1)
+            outputs[FieldHeadNames.SEMANTICS] = self.field_head_semantics(x)
+        if self.use_pred_normals:
+            pos = self.position_encoding(fr.get_positions().reshape(n, 3))
+            x = self.mlp_pred_normals(torch.cat([pos, geo], dim=-1)).view(*shape, -1)
+            outputs[FieldHeadNames.PRED_NORMALS] = self.field_head_pred_normals(x)
+        return outputs
 
     def density_fn(self, positions: Tensor) -> Tensor:
         """nerfstudio ``Field.density_fn`` (wired at R:lse_nerf/lsenerf.py:193): positions [..,3] -> density [..,1]."""

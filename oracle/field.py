@@ -281,6 +281,59 @@ class FieldOracle:
         return list(self.params.values())
 
 
+# --------------------------------------------------------------------------------------------
+# side heads of LSEField (R:lse_nerf/lse_field.py:190-252, 313-345; switched off by R:lse_nerf/lsenerf.py:168-176)
+# --------------------------------------------------------------------------------------------
+def frequency_encoding_tcnn(x: torch.Tensor, num_frequencies: int = 2) -> torch.Tensor:
+    """nerfstudio ``NeRFEncoding(..., implementation="tcnn")`` (R:lse_nerf/lse_field.py:190-192) = tcnn ``Frequency``
+    (tiny-cuda-nn, unpinned in the reference; restated from its published kernel ``frequency_encoding``): encoded feature ``j`` of
+    a point reads input dimension ``j // (2 F)``, frequency exponent ``(j // 2) % F`` and phase ``(j % 2) * pi / 2``:
+    ``sin(x * 2^e * pi + phase)``.  Loop form on purpose (the HIP-side module is vectorised)."""
+    n, d = x.shape
+    out = torch.empty(n, d * num_frequencies * 2, dtype=x.dtype)
+    for j in range(d * num_frequencies * 2):
+        i, e, ph = j // (2 * num_frequencies), (j // 2) % num_frequencies, (j % 2) * (math.pi / 2)
+        out[:, j] = torch.sin(x[:, i] * (2.0 ** e) * math.pi + ph)
+    return out
+
+
+class SideHeadsOracle:
+    """The three optional head groups on top of ``density_embedding`` (R:lse_nerf/lse_field.py:313-345), tcnn-layout MLPs +
+    nerfstudio field heads (``nn.Linear`` + Softplus / Sigmoid / none / Tanh-then-normalise).  ``params`` maps the state-dict
+    names of the reference's modules to tensors."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], geo_feat_dim=15, transient_embedding_dim=16, num_layers_transient=2,
+                 hidden_dim_transient=64):
+        self.p = params
+        self.geo = geo_feat_dim
+        self.mlp_transient = TcnnMLP(geo_feat_dim + transient_embedding_dim, num_layers_transient, hidden_dim_transient,
+                                     hidden_dim_transient, None)                                         # :213-221
+        self.mlp_semantics = TcnnMLP(geo_feat_dim, 2, 64, hidden_dim_transient, None)                    # :228-236
+        self.mlp_pred_normals = TcnnMLP(geo_feat_dim + 12, 3, 64, hidden_dim_transient, None)            # :243-251
+
+    def _head(self, name, x, act):
+        y = x @ self.p[name + ".net.weight"].t() + self.p[name + ".net.bias"]
+        return y if act is None else act(y)
+
+    def transient(self, geo, camera_indices):                                                            # :313-326
+        emb = self.p["embedding_transient.embedding.weight"][camera_indices.view(-1)]
+        x = self.mlp_transient.forward(torch.cat([geo.view(-1, self.geo), emb], dim=-1), self.p["mlp_transient.params"])
+        sp = torch.nn.functional.softplus
+        return (self._head("field_head_transient_uncertainty", x, sp), self._head("field_head_transient_rgb", x, torch.sigmoid),
+                self._head("field_head_transient_density", x, sp))
+
+    def semantics(self, geo, pass_gradients=False):                                                      # :329-335
+        inp = geo.view(-1, self.geo)
+        if not pass_gradients:
+            inp = inp.detach()
+        return self._head("field_head_semantics", self.mlp_semantics.forward(inp, self.p["mlp_semantics.params"]), None)
+
+    def pred_normals(self, positions, geo):                                                              # :338-345
+        enc = frequency_encoding_tcnn(positions.view(-1, 3))
+        x = self.mlp_pred_normals.forward(torch.cat([enc, geo.view(-1, self.geo)], dim=-1), self.p["mlp_pred_normals.params"])
+        return torch.nn.functional.normalize(self._head("field_head_pred_normals", x, torch.tanh), dim=-1)
+
+
 def _set_param(module: torch.nn.Module, name: str, value: torch.Tensor):
     parts = name.split(".")
     for p in parts[:-1]:

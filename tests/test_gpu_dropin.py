@@ -157,7 +157,8 @@ def _reference_style_model(emb_type="evs_emb", n_emb=16, seed=96):
 
 def test_reference_constructor_surface():
     """R:lse_nerf/lse_field.py:124-160: every keyword of the reference is accepted, the reference's buffers are in the
-    state dict, switched-off heads only complain when switched on, and a contraction that is not L-infinity is refused."""
+    state dict, switched-off heads add nothing, switched-on heads carry the reference's module names, and a contraction that is
+    not L-infinity is refused."""
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     f = LSEField(aabb=aabb, num_images=7, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16, base_res=16,
                  max_res=2048, log2_hashmap_size=19, num_layers_color=3, num_layers_transient=2, features_per_level=2,
@@ -168,13 +169,110 @@ def test_reference_constructor_surface():
     sd = f.state_dict()
     assert int(sd["max_res"]) == 2048 and int(sd["num_levels"]) == 16 and int(sd["log2_hashmap_size"]) == 19
     assert f.spatial_distortion.order == float("inf")
-    for kw in ("use_transient_embedding", "use_semantics", "use_pred_normals"):
-        with pytest.raises(NotImplementedError):
-            LSEField(aabb=aabb, num_images=1, **{kw: True})
+    # the heads the reference's model leaves off build the reference's modules under the reference's names when switched on
+    full = LSEField(aabb=aabb, num_images=5, use_transient_embedding=True, use_semantics=True, use_pred_normals=True,
+                    num_semantic_classes=11)
+    keys = set(full.state_dict())
+    assert {"embedding_transient.embedding.weight", "mlp_transient.params", "field_head_transient_uncertainty.net.weight",
+            "field_head_transient_rgb.net.bias", "field_head_transient_density.net.weight", "mlp_semantics.params",
+            "field_head_semantics.net.weight", "mlp_pred_normals.params", "field_head_pred_normals.net.bias"} <= keys
+    assert full.field_head_semantics.net.weight.shape == (11, 64) and not any(k.startswith("mlp_transient") for k in sd)
     with pytest.raises(NotImplementedError):
         LSEField(aabb=aabb, num_images=1, spatial_distortion=SceneContraction(order=2))
     with pytest.raises(NotImplementedError):
         LSEField(aabb=aabb, num_images=1, implementation="torch")
+
+
+def _side_head_params(fld):
+    names = ["embedding_transient.embedding.weight", "mlp_transient.params", "mlp_semantics.params", "mlp_pred_normals.params"]
+    for h in ("field_head_transient_uncertainty", "field_head_transient_rgb", "field_head_transient_density", "field_head_semantics",
+              "field_head_pred_normals"):
+        names += [h + ".net.weight", h + ".net.bias"]
+    sd = dict(fld.named_parameters())
+    return {n: sd[n] for n in names}
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_side_heads_match_oracle_and_feed_the_base_gradient(packed):
+    """R:lse_nerf/lse_field.py:313-345 with every optional head switched on: uncertainty / transient rgb / transient density,
+    semantics (gradients passed on) and predicted normals against the oracle, on stock per-sample RaySamples and on the packed
+    samples of this package's sampler (one camera index per ray); the heads' gradients reach the hash table through the geometry
+    features together with the fused RGB head's."""
+    from oracle.field import FieldOracle, SideHeadsOracle
+    from lsenerf_amd import RayBundle as HipRayBundle
+    torch.manual_seed(5)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    fld = LSEField(aabb=aabb, num_images=7, use_transient_embedding=True, use_semantics=True, pass_semantic_gradients=True,
+                   use_pred_normals=True, num_semantic_classes=11, spatial_distortion=SceneContraction(order=float("inf")))
+    with torch.no_grad():
+        fld.mlp_base_grid.params.mul_(300.0)
+    fld = fld.cuda().train()
+    g = torch.Generator().manual_seed(6)
+    if packed:
+        R = 64
+        o, d = random_rays(R, seed=3)
+        cam_ray = torch.randint(0, 7, (R, 1), generator=g)
+        occ = LSEOccGridEstimator(roi_aabb=aabb.flatten(), resolution=16, levels=1).cuda()
+        occ.binaries.fill_(True)
+        sampler = VolumetricSampler(occupancy_grid=occ, density_fn=None)
+        rb = HipRayBundle(origins=o.cuda(), directions=d.cuda(), camera_indices=cam_ray.cuda())
+        rs, ri = sampler(ray_bundle=rb, near_plane=0.05, far_plane=4.0, render_step_size=0.05, alpha_thre=0.0, cone_angle=0.0)
+        N = len(rs)
+        assert N > 500 and rs.ray_indices is not None
+        ri_c = ri.cpu().long()
+        o_s, d_s = o[ri_c], d[ri_c]
+        st, en = rs.frustums.starts.detach().cpu(), rs.frustums.ends.detach().cpu()
+        cams = cam_ray[ri_c]
+    else:
+        N = 777
+        o_s = (torch.rand(N, 3, generator=g) - 0.5) * 3
+        d_s = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+        st = torch.rand(N, 1, generator=g)
+        en = st + 0.02
+        cams = torch.randint(0, 7, (N, 1), generator=g)
+        rs = RaySamples(Frustums(o_s.cuda(), d_s.cuda(), st.cuda(), en.cuda()), camera_indices=cams.cuda(), metadata={})
+    outs = fld(rs)
+    assert set(outs) == {FieldHeadNames.RGB, FieldHeadNames.DENSITY, FieldHeadNames.UNCERTAINTY, FieldHeadNames.TRANSIENT_RGB,
+                         FieldHeadNames.TRANSIENT_DENSITY, FieldHeadNames.SEMANTICS, FieldHeadNames.PRED_NORMALS}
+    # oracle on the same samples and parameters
+    f = FieldOracle("tcnn", num_embeddings=1, contraction=True, aabb=aabb, seed=5)
+
+    class _M:       # sync_params_to_oracle reads `.field`
+        field = fld
+    sync_params_to_oracle(_M, f)
+    side_p = {n: v.detach().cpu().clone().requires_grad_(True) for n, v in _side_head_params(fld).items()}
+    side = SideHeadsOracle(side_p)
+    pos = o_s + d_s * (st + en) / 2
+    dref, geo = f.get_density(pos)
+    rref = f.get_outputs(d_s, geo, torch.zeros(N, dtype=torch.long))
+    u, trgb, tden = side.transient(geo, cams)
+    sem = side.semantics(geo, pass_gradients=True)
+    nrm = side.pred_normals(pos, geo)
+    want = {FieldHeadNames.RGB: rref, FieldHeadNames.DENSITY: dref, FieldHeadNames.UNCERTAINTY: u, FieldHeadNames.TRANSIENT_RGB: trgb,
+            FieldHeadNames.TRANSIENT_DENSITY: tden, FieldHeadNames.SEMANTICS: sem, FieldHeadNames.PRED_NORMALS: nrm}
+    for k, w in want.items():
+        assert outs[k].shape == w.shape, (k, outs[k].shape, w.shape)
+        assert nmax_err(outs[k].reshape(N, -1), w.reshape(N, -1)) < TOL_FWD, k
+    # one scalar through every head: gradients of the side parameters and of the shared trunk
+    coef = {k: torch.randn(w.shape, generator=g) for k, w in want.items()}
+    sum((outs[k] * coef[k].cuda()).sum() for k in want).backward()
+    sum((want[k] * coef[k]).sum() for k in want).backward()
+    for n, p in _side_head_params(fld).items():
+        assert nmax_err(p.grad, side_p[n].grad, 1e-12) < TOL_GRAD, n
+    assert nmax_err(fld.mlp_base_grid.params.grad, f.params["grid"].grad, 1e-12) < TOL_GRAD
+    assert nmax_err(fld.mlp_base_mlp.params.grad, f.params["base"].grad, 1e-12) < TOL_GRAD
+    assert nmax_err(fld.mlp_head.params.grad, f.params["head"].grad, 1e-12) < TOL_GRAD
+    # evaluation: the transient group is a training-only output (R:lse_nerf/lse_field.py:313)
+    fld.eval()
+    with torch.no_grad():
+        ev = fld(rs)
+    assert FieldHeadNames.UNCERTAINTY not in ev and FieldHeadNames.SEMANTICS in ev and FieldHeadNames.PRED_NORMALS in ev
+    # semantics detached from the trunk by default
+    fld2 = LSEField(aabb=aabb, num_images=1, use_semantics=True, spatial_distortion=SceneContraction(order=float("inf"))).cuda().train()
+    rs2 = RaySamples(Frustums(o_s[:64].cuda(), d_s[:64].cuda(), st[:64].cuda(), en[:64].cuda()),
+                     camera_indices=torch.zeros(64, 1, dtype=torch.long).cuda(), metadata={})
+    fld2(rs2)[FieldHeadNames.SEMANTICS].sum().backward()
+    assert fld2.mlp_semantics.params.grad is not None and fld2.mlp_base_grid.params.grad is None
 
 
 @pytest.mark.parametrize("emb_type", ["global_emb", "evs_emb"])
