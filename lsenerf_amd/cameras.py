@@ -17,7 +17,6 @@ they consume from the HIP path are d(loss)/d(origins) and d(loss)/d(directions),
 """
 from __future__ import annotations
 
-import functools
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional, Tuple
 

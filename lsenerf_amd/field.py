@@ -21,7 +21,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib, ops
-from .rays import Frustums, RaySamples
+from .rays import RaySamples
 
 
 class FieldHeadNames(Enum):

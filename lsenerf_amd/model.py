@@ -11,7 +11,6 @@ weights, rgb, accumulation and the depth numerator (the reference composes pack_
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -20,7 +19,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import ops
-from .field import FieldHeadNames, LSEEmbeddingConfig, LSEField
+from .field import LSEEmbeddingConfig, LSEField
 from .grid_estimator import LSEOccGridEstimator
 from .rays import Frustums, RayBundle, RaySamples, SceneBox, SceneContraction
 from .renderer import AccumulationRenderer, DepthRenderer, LinearRenderer, RGBRenderer

@@ -6,7 +6,7 @@ hand-written gfx950 kernels on torch's current HIP stream.  No CPU implementatio
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Tuple
 
 import ctypes
 import time

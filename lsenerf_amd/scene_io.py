@@ -21,11 +21,10 @@ from __future__ import annotations
 
 import glob
 import json
-import os
 import os.path as osp
 import warnings
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
