@@ -819,7 +819,22 @@ __global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParam
     __shared__ uint64_t s_dummy64[kWaves][64];
     __shared__ uint32_t s_perm[kWaves][64];          // rank -> lane of the run ends being staged
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wave_base = ((int64_t)blockIdx.x * kWaves + wave) * kChunk;
+    // Which 64-sample chunks a workgroup takes.  The hardware deals workgroups round-robin to the 8 XCDs, so with the identity
+    // mapping XCD x gets the chunks c = x (mod 8) -- and in ray-ordered samples the cost of a chunk depends on where on its ray it
+    // lies (dense cells near the camera, long runs in the contracted shell): with 1024 samples per ray XCD x saw the chunks x and
+    // x + 8 of EVERY ray, a static load imbalance between XCDs.  Workgroup b therefore takes position (b % 8) * ceil(B / 8) + b / 8
+    // of the B positions the samples actually fill (device-side count: a captured step's capacity is larger): every XCD walks one
+    // contiguous eighth, i.e. whole rays whatever their length.  Inside-box rays 2.39 -> 2.19 ms, the reference's default
+    // configuration 1.51 -> 1.47, headline +-0.3 % (profiles/r05_hash_bwd_xcd_mapping.txt).  (dbg & 32, development build: the
+    // identity mapping, for A/B.)
+    int64_t wg = blockIdx.x;
+    if (!(dbg & 32)) {
+        const int64_t positions = (n + (int64_t)kChunk * kWaves - 1) / ((int64_t)kChunk * kWaves);
+        const int64_t per_xcd = (positions + 7) >> 3;
+        if ((wg >> 3) >= per_xcd) return;      // (the grid covers the capacity, rounded up to a multiple of 8)
+        wg = (wg & 7) * per_xcd + (wg >> 3);
+    }
+    const int64_t wave_base = (wg * kWaves + wave) * kChunk;
     if (wave_base >= n) return;
     lds_u32 *key = (lds_u32 *)&s_key[wave][0];
     lds_f32 *val = (lds_f32 *)&s_val[wave][0];
@@ -1663,14 +1678,14 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
     for (int l = 0; l <= g.n_levels; ++l) lines_ok = lines_ok && (g.offsets[l] % 8 == 0);
     LSE_REQUIRE(!n_dev || lines_ok, "lse_hash_bwd: a device-side count needs 64-byte aligned levels (the default kernel)");
     if (impl == 2 && lines_ok) {     // per-wave sector cache with run ends of several levels batched into one pass
-        const int64_t blocks = (n + 4 * 64 - 1) / (4 * 64);
+        const int64_t blocks = ((n + 4 * 64 - 1) / (4 * 64) + 7) / 8 * 8;      // (four-wave development variants; chunk mapping: a multiple of 8)
         LSE_REQUIRE(blocks < (1ll << 31), "lse_hash_bwd: grid too large");
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         // (workgroups of WAVES waves with SLOTS cache slots per wave; nothing in the kernel synchronises across waves)
 #define LSE_HASH_BWD_LAUNCH(SLOTS, WAVES)                                                                                              \
         {                                                                                                                                 \
-            const int64_t bl = (n + (WAVES) * 64 - 1) / ((WAVES) * 64);                                                                   \
+            const int64_t bl = ((n + (WAVES) * 64 - 1) / ((WAVES) * 64) + 7) / 8 * 8;      /* (chunk mapping: a multiple of 8) */          \
             LSE_REQUIRE(bl < (1ll << 31), "lse_hash_bwd: grid too large");                                                                \
             if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, SLOTS, 2, true, true, false, false, WAVES>), dim3((unsigned)bl),    \
                                        dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe,       \
