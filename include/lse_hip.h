@@ -209,7 +209,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *   impl          2 = lane-per-sample kernel, per-wave LDS sector cache keyed by GLOBAL sector id, the run ends of several
  *                     levels batched into one cache pass (default); 1 = one cache pass per level; 0 = 16-lanes-per-sample kernel
  *   stage_max     impl 2: with an empty queue, a level that ends more than stage_max runs in the wave passes unstaged (default 48;
- *                     32 is better when the step size is constant: profiles/r05_hash_bwd_thresholds.txt)
+ *                     56 is better when the step size is constant: profiles/r05_hash_bwd_thresholds_final.txt)
  *   gran          cache slots: 2 = 512 slots of one 32-B sector; 3 (impl 1 only) = 256 slots of one 64-B line; 4 (impl 2) =
  *                     512 sector slots PAIRED by 64-B line, flushed in slot order -- a float-atomic request costs the same for 4 .. 64
  *                     contiguous bytes (tools/micro/atomic_gran.hip), so sibling sectors leave as one request; 5 = the same with
@@ -220,7 +220,7 @@ int lse_hash_bwd_levels(const lse_grid_desc *desc, const float *x01, const float
  *                     development build only: 8 = 6 with 320 slots in workgroups of four waves (12 waves per CU), 9 / 11 = 384
  *                     slots in workgroups of two / one waves (10 / 9 waves per CU), 10 = 448 slots, one wave (9 waves per CU),
  *                     12 / 13 = 512 slots in workgroups of four (the shape until round 5) / two waves
- *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 8; 6 is better when
+ *   few_runs      impl 1, 2: a wave that ends <= few_runs runs at a level adds them straight to memory (default 8; 3 is better when
  *                     the step size is constant)
  *   second_probe  impl 1, 2: extra probe rounds (home slot + k * step, k = 1 .. second_probe) before a corner falls back to memory (default 3)
  *   rounds        impl 0: 16 / 32 / 64 rounds of 4 samples per wave (default 32)

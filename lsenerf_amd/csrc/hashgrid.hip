@@ -1526,7 +1526,7 @@ extern "C" void lse_hash_bwd_default_opts(lse_hash_bwd_opts *o)
                            // flush, 2 = unpaired); impl 1: 2 / 3
     o->few_runs = (int32_t)lse::option("hash_bwd_few_runs");     // 8 (round 5, profiles/r05_hash_bwd_thresholds.txt: with stage_max 48 the best pair for steps
                            // that grow with the distance -- the reference's default configuration 1.51 -> 1.43 ms -- and neutral
-                           // (+0.2 %) at the metric size, whose constant step prefers (6, 32): 2.59 -> 2.56 ms; callers that know the
+                           // (+0.2 %) at the metric size, whose constant step prefers fewer direct adds -- (3, 56) on the final kernel; callers that know the
                            // regime pass the pair (lsenerf_amd/ops.py: HASH_BWD_DENSE_STEPS); 10 and 16: slower everywhere)
     o->second_probe = (int32_t)lse::option("hash_bwd_probes");   // extra probe rounds (home + k * step) before a corner goes to memory
                            // alone; pays wherever the kernel is bound by atomic requests, costs ~2 % per round where it is issue-bound.

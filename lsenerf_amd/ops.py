@@ -473,10 +473,13 @@ def direct_grad_params(module: torch.nn.Module) -> Optional[dict]:
 # Path-selection thresholds of the hash backward by sample regime (profiles/r05_hash_bwd_thresholds.txt, MI355X): a wave that ends
 # <= few_runs runs at a level adds them straight to memory; a level that ends > stage_max runs passes the sector cache unstaged.
 #   constant step (cone_angle == 0: consecutive samples walk through cells at a fixed pace, the run-end count grows smoothly from
-#   level to level and the queue fills well): (6, 32) -- headline 2.59 -> 2.56 ms, inside-box 2.70 -> 2.63, M-packed +-0;
+#   level to level and the queue fills well): (3, 56) -- re-tuned on the round-5 kernel (leaner cache pass, one wave per workgroup,
+#   whole rays per XCD: a cache pass got cheaper than the direct adds it replaces), profiles/r05_hash_bwd_thresholds_final.txt:
+#   against (6, 32) headline 2.53 -> 2.46 ms, inside-box 2.19 -> 2.14, M-packed 3.03 -> 2.96; (2, 64) is 0.6 % better at the
+#   headline and 2 % worse on M-packed, and few_runs 1 falls off a cliff (2.69);
 #   steps that grow with the distance (cone_angle > 0, the reference's default: sparser samples, more run ends per level):
-#   (8, 48) = the library's defaults -- default configuration 1.51 -> 1.43 ms.
-HASH_BWD_DENSE_STEPS = (("few_runs", 6), ("stage_max", 32))
+#   (8, 48) = the library's defaults -- default configuration 1.51 -> 1.43 ms (still the best pair on the final kernel).
+HASH_BWD_DENSE_STEPS = (("few_runs", 3), ("stage_max", 56))
 HASH_BWD_DEFAULT = ()
 
 

@@ -264,4 +264,4 @@ def test_the_model_hands_its_sample_regime_to_the_hash_backward(monkeypatch):
         m.exec_get_outputs(rb)["rgb"].sum().backward()
         assert m.field.mlp_base_grid.dense_steps is want_dense
         assert m.field.mlp_base_grid.meta.bwd_tuning == (ops.HASH_BWD_DENSE_STEPS if want_dense else ops.HASH_BWD_DEFAULT)
-    assert seen == [(6, 32), (8, 48)], seen
+    assert seen == [(3, 56), (8, 48)], seen

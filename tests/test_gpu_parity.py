@@ -429,7 +429,7 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
                 "prefetch": {"prefetch": 1}, "prefetch_no_few_runs": {"prefetch": 1, "few_runs": 0}, "prefetch_stage_all": {"prefetch": 1, "stage_max": 64},
                 "prefetch_coarse5": {"prefetch": 1, "coarse_levels": 5},
                 # pair-aligned flush lists
-                "few_runs8": {"few_runs": 8}, "dense_steps_thresholds": {"few_runs": 6, "stage_max": 32}, "round4_thresholds": {"few_runs": 6, "stage_max": 16},
+                "few_runs8": {"few_runs": 8}, "dense_steps_thresholds": {"few_runs": 3, "stage_max": 56}, "round5_first_thresholds": {"few_runs": 6, "stage_max": 32}, "few_runs2_stage_all": {"few_runs": 2, "stage_max": 64}, "round4_thresholds": {"few_runs": 6, "stage_max": 16},
                 # 320 slots (52 KB of LDS per workgroup: three workgroups = 12 waves per CU; non-power-of-two slot arithmetic)
                 # the compute half of two levels issued together (development build)
                 "slots320": {"gran": 8}, "slots320_dense_steps": {"gran": 8, "few_runs": 6, "stage_max": 32}, "slots320_probe0": {"gran": 8, "second_probe": 0},
