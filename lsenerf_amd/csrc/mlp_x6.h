@@ -1269,6 +1269,46 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void mlp_bwd3_kernel(MlpArgs
         LSE_PHASE("end");
     }
     if (BIAS_ONES) flush_bias_col();
+    // Weight gradients: the NW waves of the workgroup first sum their accumulators through LDS (the weight images and tiles are dead
+    // by now) -- a tree of plain 16-byte writes and reads, three rounds for eight waves -- and ONE wave adds the sums to memory.
+    // Until round 5 every wave sent its own: 2048 waves x 384 (head) / 192 (base) 64-byte float-atomic requests onto the same
+    // few hundred lines, 1.2 M requests per step at the memory side's 21 G/s = the better part of the ~60 us a launch of this
+    // kernel cost whatever its size (tools/mlp_bwd_fixed_cost.py).
+    constexpr int SLOTS = HB * KB0 + ((NHL == 2) ? HB * HB : 0) + HB;
+    // (development shapes with 12 waves per workgroup keep the per-wave flush)
+    if constexpr (NW > 1 && (NW & (NW - 1)) == 0 && (NW / 2) * SLOTS * 64 * 16 <= C::lds_bytes) {
+        f32x4 *red = reinterpret_cast<f32x4 *>(lds);
+        auto each_acc = [&](auto fn) {      // fn(accumulator tile, slot)
+            int slot = 0;
+#pragma unroll
+            for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+                for (int kb = 0; kb < KB0; ++kb) fn(acc0[mb][kb], slot++);
+            if constexpr (NHL == 2) {
+#pragma unroll
+                for (int mb = 0; mb < HB; ++mb)
+#pragma unroll
+                    for (int kb = 0; kb < HB; ++kb) fn(acc1[mb][kb], slot++);
+            }
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) fn(accO[0][kb], slot++);
+        };
+        __syncthreads();      // every wave is done with the weight images and its tiles
+#pragma unroll
+        for (int half = NW / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+                f32x4 *dst = red + (size_t)(wave - half) * SLOTS * 64 + lane;
+                each_acc([&](f32x4 &t, int slot) { dst[slot * 64] = t; });
+            }
+            __syncthreads();
+            if (wave < half) {
+                const f32x4 *src = red + (size_t)wave * SLOTS * 64 + lane;
+                each_acc([&](f32x4 &t, int slot) { t += src[slot * 64]; });
+            }
+            if (half > 1) __syncthreads();      // the next round's writers wait for this round's readers
+        }
+        if (wave != 0) return;
+    }
     flush_wgrad<HB, KB0>(a.d_params + a.w0_col, a.w0_ld, KIN, acc0, j, q, a.w0_mask0 != 0);
     if constexpr (NHL == 2) flush_wgrad<HB, HB>(a.d_params + a.rest_off, WIDTH, WIDTH, acc1, j, q);
     flush_wgrad<1, HB>(a.d_params + a.rest_off + (NHL - 1) * WIDTH * WIDTH, WIDTH, WIDTH, accO, j, q);
