@@ -474,6 +474,50 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
             check("dev:" + name, kw)
 
 
+def test_hash_bwd_chunk_mapping_covers_every_sample_count():
+    """The default hash backward hands workgroup b the chunk (b % 8) * ceil(B / 8) + b / 8 of the B chunks the samples fill (every
+    XCD walks one contiguous eighth) and launches a multiple of 8 workgroups over the CAPACITY: sample counts around the chunk
+    (64) and 8-chunk borders, and device-side counts anywhere between 0 and the capacity, must each be covered exactly once --
+    checked against the oracle (host counts) and against the same call on the truncated arrays (device counts)."""
+    import ctypes
+    from oracle import hashgrid as ohg
+    from lsenerf_amd import _lib
+    ops = _ops()
+    meta_o = ohg.tcnn_grid_meta(n_levels=16, log2_hashmap_size=15)
+    meta = ops.make_grid_meta(n_levels=16, log2_hashmap_size=15)
+    g = torch.Generator().manual_seed(12)
+    table = (torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.1
+    cap = 64 * 8 * 3 + 200
+    x_all = _ray_coherent_points(4, (cap + 3) // 4, seed=5)[:cap].contiguous()
+    w_all = torch.randn(cap, 32, generator=g)
+    tg = table.cuda()
+    for n in (1, 63, 64, 65, 64 * 7 + 1, 64 * 8, 64 * 8 + 1, 64 * 9 - 1, 64 * 16 + 17, cap):
+        x, w = x_all[:n].contiguous(), w_all[:n].contiguous()
+        tc = table.clone().requires_grad_(True)
+        (ohg.hash_encode_tcnn(x, tc, meta_o) * w).sum().backward()
+        dy = w.reshape(n, 16, 2).permute(1, 0, 2).contiguous().cuda()
+        dt, _ = _hash_bwd_ex(ops, meta, x.cuda(), dy, tg)
+        assert nmax_err(dt, tc.grad) < TOL_GRAD, n
+        assert rel_l2(dt, tc.grad) < TOL_GRAD, n
+    # device-side counts: arrays of capacity extent, dy with the capacity as its level stride
+    xg = x_all.cuda()
+    dy_cap = w_all.reshape(cap, 16, 2).permute(1, 0, 2).contiguous().cuda()
+    desc = meta.desc()
+    P = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
+    for n_dev in (0, 1, 64, 65, 64 * 8 - 1, 64 * 8, 64 * 8 + 1, 1000, cap - 1, cap, cap + 77):
+        cnt = torch.tensor([n_dev], dtype=torch.int64, device="cuda")
+        dt = torch.zeros_like(tg); dx = torch.full_like(xg, 7.0)
+        _lib.call("lse_hash_bwd", ctypes.byref(desc), P(xg), P(dy_cap), P(tg), P(dt), P(dx), cap, P(cnt), ops._stream())
+        m = min(n_dev, cap)
+        if m == 0:
+            assert not bool(dt.any())
+            continue
+        dt_ref, dx_ref = _hash_bwd_ex(ops, meta, xg[:m].contiguous(), dy_cap[:, :m].contiguous(), tg)
+        assert nmax_err(dt, dt_ref) < 1e-5, n_dev          # same kernel, other launch extent: summation order only
+        assert torch.allclose(dx[:m], dx_ref, rtol=1e-5, atol=1e-7), n_dev
+        assert bool((dx[m:] == 7.0).all()), n_dev          # nothing beyond the device-side count is written
+
+
 def test_hash_full_size_forward_subset_and_backward_linearity():
     """BASELINE size: N = 2^22 ray-coherent samples, T = 2^19.  The oracle evaluates a 2^16-sample random subset of the
     forward and of d(x); the table gradient is checked through linearity of the encoding in the table:
