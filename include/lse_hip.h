@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LSE_ABI_VERSION 5
+#define LSE_ABI_VERSION 6
 
 #define LSE_OK 0
 #define LSE_E_INVALID (-1)   /* bad argument (null pointer, unsupported size) */
@@ -367,10 +367,26 @@ int lse_occ_binarize(const float *occs, int64_t n, const float *d_threshold, uin
  * Event bundles (prev, next):  c = max(rgb, 1e-5);  ev_one_dim != NONE: m_evs(sum_k w_k c_k) with w = softmax(w31)
  *   (ThreeToOne, LEARNED) or the gray vector (GRAY);  NONE: gray(m_evs(c));  L = log(. + 1e-6);
  *   event_loss = evs_loss_weight * mean (L_next - L_prev - evs_gt)^2          (log_loss).
- * m = identity | x^(1/2.4) ("gt") | x^p ("powpow", p = *pow_rgb / *pow_evs, learnable). */
+ * m = identity | x^(1/2.4) ("gt") | x^p ("powpow", p = *pow_rgb / *pow_evs, learnable) | "mlp" | "rgb_mlp" (ABI 6): the
+ *   identity-initialised nerfstudio MLP(in, num_layers = 4, layer_width = 16, out = in, ReLU, out_activation = Sigmoid) of
+ *   R:lse_nerf/intensity_mappers.py:28-62 -- "mlp" maps ONE channel (in = 1: the event side behind ev_one_dim; on three channels
+ *   the reference's nn.Linear(1, 16) raises, and so does the call), "rgb_mlp" the three channels together (in = 3: the colour
+ *   side, or the event side with ev_one_dim == NONE).  Their parameters come as lse_mapper_mlp. */
 #define LSE_MAP_IDENTITY 1
 #define LSE_MAP_GT 2
 #define LSE_MAP_POWPOW 3
+#define LSE_MAP_MLP 4
+#define LSE_MAP_RGB_MLP 5
+/* The four nn.Linear layers of an MLP mapper, in = 1 ("mlp") | 3 ("rgb_mlp"): w[l] row-major [out][in] = [16,in] [16,16] [16,16]
+ * [in,16], b[l] = [16] [16] [16] [in] (device pointers; the struct itself is host memory, read during the call).  dw / db: the
+ * gradients, same shapes, ACCUMULATED into (+=) by lse_loss_epilogue_bwd in a fixed order (no atomics); all eight NULL = not
+ * wanted; the forward ignores them. */
+typedef struct lse_mapper_mlp {
+    const float *w[4];
+    const float *b[4];
+    float *dw[4];
+    float *db[4];
+} lse_mapper_mlp;
 #define LSE_ONE_DIM_NONE 0
 #define LSE_ONE_DIM_LEARNED 1
 #define LSE_ONE_DIM_GRAY 2
@@ -383,17 +399,20 @@ typedef struct lse_epilogue_desc {
     float evs_loss_weight;
 } lse_epilogue_desc;
 /* losses[2] = (rgb_loss, event_loss); a bundle whose pointer is NULL contributes 0.  Deterministic (no atomics). */
+/* mlp_rgb / mlp_evs: parameters of the colour-side / event-side mapper when its kind is LSE_MAP_MLP / LSE_MAP_RGB_MLP (else ignored,
+ * NULL allowed). */
 int lse_loss_epilogue_fwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
                           const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
-                          const float *pow_rgb, const float *pow_evs, const float *w31, float *losses,
-                          lse_stream_t stream);
+                          const float *pow_rgb, const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb,
+                          const lse_mapper_mlp *mlp_evs, float *losses, lse_stream_t stream);
 /* g_rgb_loss / g_event_loss: device scalars, the upstream gradients of the two losses (NULL = 0).  d_col [n_col*deblur_group,3], d_prev / d_next [n_ev,3]
- * (each nullable) are overwritten; d_scalars[5] = (d pow_rgb, d pow_evs, d w31[3]) is overwritten. */
+ * (each nullable) are overwritten; d_scalars[5] = (d pow_rgb, d pow_evs, d w31[3]) is overwritten; the gradients of an MLP mapper's
+ * parameters are accumulated into mlp_*->dw / db. */
 int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
                           const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
-                          const float *pow_rgb, const float *pow_evs, const float *w31, const float *g_rgb_loss,
-                          const float *g_event_loss, float *d_col, float *d_prev, float *d_next, float *d_scalars,
-                          lse_stream_t stream);
+                          const float *pow_rgb, const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb,
+                          const lse_mapper_mlp *mlp_evs, const float *g_rgb_loss, const float *g_event_loss, float *d_col,
+                          float *d_prev, float *d_next, float *d_scalars, lse_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam semantics on a flat buffer (R:lse_nerf/lse_config.py:29-33) ----------- */
 int lse_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,

@@ -19,7 +19,7 @@ LSE_MAX_GRID_LEVELS = 32
 LSE_MAX_OCC_LEVELS = 8
 LSE_IN_ROWMAJOR, LSE_IN_LEVELMAJOR = 0, 1
 LSE_ACT_NONE, LSE_ACT_SIGMOID = 0, 1
-LSE_ABI_VERSION = 5
+LSE_ABI_VERSION = 6
 LSE_MLP_ARITH_AUTO, LSE_MLP_ARITH_F32_MFMA = 0, 1
 LSE_TRAVERSE_FMA_SETUP = 1
 
@@ -41,7 +41,14 @@ class EpilogueDesc(Structure):
                 ("deblur_group", c_int32), ("evs_loss_weight", c_float)]
 
 
-LSE_MAP_IDENTITY, LSE_MAP_GT, LSE_MAP_POWPOW = 1, 2, 3
+LSE_MAP_IDENTITY, LSE_MAP_GT, LSE_MAP_POWPOW, LSE_MAP_MLP, LSE_MAP_RGB_MLP = 1, 2, 3, 4, 5
+
+
+class MapperMlp(Structure):
+    """lse_mapper_mlp: the four nn.Linear layers of an MLP intensity mapper (device pointers) and where their gradients go."""
+    _fields_ = [("w", c_void_p * 4), ("b", c_void_p * 4), ("dw", c_void_p * 4), ("db", c_void_p * 4)]
+
+
 LSE_ONE_DIM_NONE, LSE_ONE_DIM_LEARNED, LSE_ONE_DIM_GRAY = 0, 1, 2
 
 
@@ -91,8 +98,9 @@ SIGNATURES = {
     "lse_volrend_depth_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P, P],
     "lse_render_weight_fwd": [P, P, P, P, I32, P, P, P, P],
     "lse_render_weight_bwd": [P, P, P, P, I32, P, P, P, P],
-    "lse_loss_epilogue_fwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, P, P],
-    "lse_loss_epilogue_bwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, P, P, P, P, P, P, P],
+    "lse_loss_epilogue_fwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp), P, P],
+    "lse_loss_epilogue_bwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp),
+                              P, P, P, P, P, P, P],
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],
     "lse_adam_step": [P, P, P, P, I64, F32, F32, F32, F32, I32, F32, P],

@@ -191,6 +191,8 @@ def identity_init(mlp: nn.Module, in_dim: int = 3, out_dim: int = 3, n_steps: in
             opt.zero_grad()
             loss.backward()
             opt.step()
+    for p in mlp.parameters():      # the fit's last gradient is not a training gradient: the first step accumulates from nothing
+        p.grad = None
     return mlp
 
 
@@ -218,8 +220,8 @@ class RGB_MLP_Mapper(nn.Module):
         return self.mlp(x)
 
 
-# R:lse_nerf/intensity_mappers.py:93-97.  The MLP mappers act on per-ray values (O(R)); the fused loss epilogue covers the
-# closed-form ones and hands configurations with an MLP mapper to the torch routing (``_epilogue_desc`` returns None).
+# R:lse_nerf/intensity_mappers.py:93-97.  All five run inside the fused loss epilogue (the MLP mappers since ABI 6:
+# csrc/epilogue.hip, epilogue_mlp_* kernels); the modules' own forward() serves evaluation and the torch route.
 MAPPERS_DICT = {"mlp": MLP_Mapper, "rgb_mlp": RGB_MLP_Mapper, "gt": GT_Mapper, "identity": IdentityMapper, "powpow": Powpow}
 format_linear = lambda x: torch.concatenate([x] * 3, dim=-1) if x.shape[-1] == 1 else x
 
@@ -688,22 +690,31 @@ class LSENeRFModel(nn.Module):
                                      cone_angle=cfg.cone_angle, jitter=jitter, out=out)
 
     # -- fused training epilogue -----------------------------------------------------------------------------
-    def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor]]]:
-        """(descriptor fields, pow_rgb, pow_evs, w31) for ops.loss_epilogue, or None when the configuration needs the torch
-        route (MLP mappers, enerf_norm_loss, or the event loss reading a deblur-averaged "rgb")."""
+    def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor], tuple, tuple]]:
+        """(descriptor fields, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs) for ops.loss_epilogue, or None when the configuration needs
+        the torch route (enerf_norm_loss, an unrouted map_mode, the event loss reading a deblur-averaged "rgb", or an MLP mapper on a
+        channel count its first nn.Linear does not take -- the reference raises there, and so does the torch route).  ``mlp_*``: the
+        eight parameters of an MLP mapper on that side in module order (R:lse_nerf/intensity_mappers.py:28-62), () otherwise."""
         from . import _lib
         cfg, plan = self.config, self._plan()
         kinds = {IdentityMapper: _lib.LSE_MAP_IDENTITY, GT_Mapper: _lib.LSE_MAP_GT, Powpow: _lib.LSE_MAP_POWPOW,
-                 type(None): _lib.LSE_MAP_IDENTITY}
+                 MLP_Mapper: _lib.LSE_MAP_MLP, RGB_MLP_Mapper: _lib.LSE_MAP_RGB_MLP, type(None): _lib.LSE_MAP_IDENTITY}
         if plan["unrouted"] or cfg.event_loss_type.lower() != "log_loss" or type(plan["rgb_mapper"]) not in kinds \
                 or type(plan["ev_mapper"]) not in kinds or (plan["ev_key"] == "rgb" and plan["deblur_group"] > 1):
             return None
         od = plan["ev_one_dim"]
         one_dim = _lib.LSE_ONE_DIM_NONE if od is None else (_lib.LSE_ONE_DIM_LEARNED if isinstance(od, ThreeToOne) else _lib.LSE_ONE_DIM_GRAY)
-        fields = (int(plan["rgb_mapper"] is not None), kinds[type(plan["rgb_mapper"])], kinds[type(plan["ev_mapper"])], one_dim,
-                  plan["deblur_group"], float(cfg.evs_loss_weight))
+        rgb_kind, evs_kind = kinds[type(plan["rgb_mapper"])], kinds[type(plan["ev_mapper"])]
+        one_channel = one_dim != _lib.LSE_ONE_DIM_NONE
+        if rgb_kind == _lib.LSE_MAP_MLP or (evs_kind == _lib.LSE_MAP_MLP and not one_channel) \
+                or (evs_kind == _lib.LSE_MAP_RGB_MLP and one_channel):
+            return None           # nn.Linear(1, 16) on three channels / nn.Linear(3, 16) on one
+        fields = (int(plan["rgb_mapper"] is not None), rgb_kind, evs_kind, one_dim, plan["deblur_group"], float(cfg.evs_loss_weight))
         coeff = lambda m: m.pow_coeff if isinstance(m, Powpow) else None
-        return fields, coeff(plan["rgb_mapper"]), coeff(plan["ev_mapper"]), (od.weights if isinstance(od, ThreeToOne) else None)
+        layers = lambda m: tuple(p for layer in m.mlp.layers for p in (layer.weight, layer.bias)) \
+            if isinstance(m, (MLP_Mapper, RGB_MLP_Mapper)) else ()
+        return (fields, coeff(plan["rgb_mapper"]), coeff(plan["ev_mapper"]), (od.weights if isinstance(od, ThreeToOne) else None),
+                layers(plan["rgb_mapper"]), layers(plan["ev_mapper"]))
 
     def fused_loss_dict(self, raw_outputs: Dict[str, Optional[Dict[str, Tensor]]], batch,
                         packed_rgb: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -717,12 +728,12 @@ class LSENeRFModel(nn.Module):
         desc = self._epilogue_desc()
         col, prev, nxt = (raw_outputs.get(k) for k in ("col_out", "prev_out", "next_out"))
         if desc is not None and packed_rgb is not None:
-            fields, pow_rgb, pow_evs, w31 = desc
+            fields, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs = desc
             n_col = col["rgb"].shape[0] if col is not None else 0
             n_ev = prev["rgb"].shape[0] if prev is not None else 0
             rgb_loss, event_loss = ops.loss_epilogue_packed(
                 fields, packed_rgb, n_col, n_ev, batch["col_batch"]["image"] if col is not None else None,
-                batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31)
+                batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs)
             losses = {}
             if col is not None:
                 losses["rgb_loss"] = rgb_loss
@@ -733,11 +744,11 @@ class LSENeRFModel(nn.Module):
             routed = {k: (self.route_outputs(v, None, ev_out=(k != "col_out")) if v is not None else None)
                       for k, v in (("col_out", col), ("prev_out", prev), ("next_out", nxt))}
             return self.get_loss_dict(routed, batch)
-        fields, pow_rgb, pow_evs, w31 = desc
+        fields, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs = desc
         rgb_loss, event_loss = ops.loss_epilogue(
             fields, col["rgb"] if col is not None else None, batch["col_batch"]["image"] if col is not None else None,
             prev["rgb"] if prev is not None else None, nxt["rgb"] if nxt is not None else None,
-            batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31)
+            batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs)
         losses = {}
         if col is not None:
             losses["rgb_loss"] = rgb_loss

@@ -1002,9 +1002,52 @@ def volume_render_depth(t_starts, t_ends, sigmas, rgb, packed_info):
 # ----------------------------------------------------------------------------------------------------
 # training epilogue: routing + mappers + losses
 # ----------------------------------------------------------------------------------------------------
+def _mapper_mlp_shapes(in_dim: int):
+    return [(16, in_dim), (16,), (16, 16), (16,), (16, 16), (16,), (in_dim, 16), (in_dim,)]
+
+
+def _mapper_mlp_struct(params, grads=None) -> Optional["_lib.MapperMlp"]:
+    """lse_mapper_mlp of an MLP intensity mapper: ``params`` = its eight tensors in module order (layers.0.weight, layers.0.bias,
+    ... layers.3.bias: nn.Linear layout), ``grads`` = the eight buffers the backward accumulates into."""
+    if not params:
+        return None
+    in_dim = params[0].shape[1]
+    if len(params) != 8 or in_dim not in (1, 3) or [tuple(p.shape) for p in params] != _mapper_mlp_shapes(in_dim):
+        raise ValueError(f"MLP mapper parameters {[tuple(p.shape) for p in params]}: expected the four nn.Linear layers of "
+                         f"MLP(in, num_layers=4, layer_width=16, out=in), in = 1 | 3")
+    m = _lib.MapperMlp()
+    for l in range(4):
+        m.w[l] = _f32(params[2 * l], f"mlp.w[{l}]").value
+        m.b[l] = _f32(params[2 * l + 1], f"mlp.b[{l}]").value
+        if grads is not None:
+            m.dw[l] = _f32(grads[2 * l], f"mlp.dw[{l}]").value
+            m.db[l] = _f32(grads[2 * l + 1], f"mlp.db[{l}]").value
+    return m
+
+
+def _mapper_mlp_grads(params):
+    """(buffers the kernel accumulates into, what the autograd Function returns for the eight inputs): a parameter whose .grad is
+    preallocated (optim.FlatParams) takes its gradient there and the Function returns None for it (``_direct_grad``)."""
+    bufs, rets = [], []
+    for p in params:
+        direct = _direct_grad(p)
+        if direct is not None:
+            bufs.append(direct)
+            rets.append(None)
+        else:
+            g = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            bufs.append(g)
+            rets.append(g)
+    return bufs, tuple(rets)
+
+
+def _byref(struct):
+    return ctypes.byref(struct) if struct is not None else None
+
+
 class _LossEpilogueFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, desc_fields, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31):
+    def forward(ctx, desc_fields, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, n_mlp_rgb=0, *mlp_params):
         dev = (col_rgb if col_rgb is not None else prev_rgb).device
         desc = _lib.EpilogueDesc(*desc_fields)
         group = desc.deblur_group
@@ -1016,17 +1059,20 @@ class _LossEpilogueFn(torch.autograd.Function):
         _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
                   n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _byref(_mapper_mlp_struct(mlp_params[:n_mlp_rgb])), _byref(_mapper_mlp_struct(mlp_params[n_mlp_rgb:])),
                   ctypes.c_void_p(losses.data_ptr()), _stream())
-        ctx.save_for_backward(col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31)
-        ctx.desc_fields, ctx.n_col, ctx.n_ev = desc_fields, n_col, n_ev
+        ctx.save_for_backward(col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, *mlp_params)
+        ctx.desc_fields, ctx.n_col, ctx.n_ev, ctx.n_mlp_rgb = desc_fields, n_col, n_ev, n_mlp_rgb
         ctx.set_materialize_grads(False)
         return losses[0], losses[1]
 
     @staticmethod
     def backward(ctx, g_rgb, g_evs):
-        col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31 = ctx.saved_tensors
+        col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, *mlp_params = ctx.saved_tensors
         dev = (col_rgb if col_rgb is not None else prev_rgb).device
         desc = _lib.EpilogueDesc(*ctx.desc_fields)
+        mlp_bufs, mlp_rets = _mapper_mlp_grads(mlp_params)
+        k = ctx.n_mlp_rgb
         g_rgb = g_rgb.reshape(1).contiguous().float() if g_rgb is not None else None
         g_evs = g_evs.reshape(1).contiguous().float() if g_evs is not None else None
         d_col = torch.empty_like(col_rgb) if col_rgb is not None else None
@@ -1036,9 +1082,10 @@ class _LossEpilogueFn(torch.autograd.Function):
         _lib.call("lse_loss_epilogue_bwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   ctx.n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
                   ctx.n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _byref(_mapper_mlp_struct(mlp_params[:k], mlp_bufs[:k])), _byref(_mapper_mlp_struct(mlp_params[k:], mlp_bufs[k:])),
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(d_col, "d_col", True),
                   _f32(d_prev, "d_prev", True), _f32(d_next, "d_next", True), ctypes.c_void_p(d_sc.data_ptr()), _stream())
-        return (None, d_col, None, d_prev, d_next, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31)
+        return (None, d_col, None, d_prev, d_next, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None,) + mlp_rets
 
 
 def _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31):
@@ -1071,7 +1118,7 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
     3-bundle step, tools/graph_timeline.py)."""
 
     @staticmethod
-    def forward(ctx, desc_fields, rgb_all, n_col_rays, n_ev, col_gt, evs_gt, pow_rgb, pow_evs, w31):
+    def forward(ctx, desc_fields, rgb_all, n_col_rays, n_ev, col_gt, evs_gt, pow_rgb, pow_evs, w31, n_mlp_rgb=0, *mlp_params):
         dev = rgb_all.device
         desc = _lib.EpilogueDesc(*desc_fields)
         group = desc.deblur_group
@@ -1087,17 +1134,20 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
         _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   n_col_rays // group, _f32(prev, "prev_rgb", True), _f32(nxt, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
                   n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _byref(_mapper_mlp_struct(mlp_params[:n_mlp_rgb])), _byref(_mapper_mlp_struct(mlp_params[n_mlp_rgb:])),
                   ctypes.c_void_p(losses.data_ptr()), _stream())
-        ctx.save_for_backward(rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31)
-        ctx.desc_fields, ctx.n_col_rays, ctx.n_ev = desc_fields, n_col_rays, n_ev
+        ctx.save_for_backward(rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, *mlp_params)
+        ctx.desc_fields, ctx.n_col_rays, ctx.n_ev, ctx.n_mlp_rgb = desc_fields, n_col_rays, n_ev, n_mlp_rgb
         ctx.set_materialize_grads(False)
         return losses[0], losses[1]
 
     @staticmethod
     def backward(ctx, g_rgb, g_evs):
-        rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31 = ctx.saved_tensors
+        rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, *mlp_params = ctx.saved_tensors
         dev = rgb_all.device
         desc = _lib.EpilogueDesc(*ctx.desc_fields)
+        mlp_bufs, mlp_rets = _mapper_mlp_grads(mlp_params)
+        k = ctx.n_mlp_rgb
         n0, ne = ctx.n_col_rays, ctx.n_ev
         g_rgb = g_rgb.reshape(1).contiguous().float() if g_rgb is not None else None
         g_evs = g_evs.reshape(1).contiguous().float() if g_evs is not None else None
@@ -1107,26 +1157,32 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
                   n0 // desc.deblur_group, _f32(part(rgb_all, n0, n0 + ne), "prev_rgb", True),
                   _f32(part(rgb_all, n0 + ne, n0 + 2 * ne), "next_rgb", True), _f32(evs_gt, "evs_gt", True), ne,
                   _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _byref(_mapper_mlp_struct(mlp_params[:k], mlp_bufs[:k])), _byref(_mapper_mlp_struct(mlp_params[k:], mlp_bufs[k:])),
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(part(d_all, 0, n0), "d_col", True),
                   _f32(part(d_all, n0, n0 + ne), "d_prev", True), _f32(part(d_all, n0 + ne, n0 + 2 * ne), "d_next", True),
                   ctypes.c_void_p((d_sc := torch.empty(5, dtype=torch.float32, device=dev)).data_ptr()), _stream())
-        return (None, d_all, None, None, None, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31)
+        return (None, d_all, None, None, None, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None,) + mlp_rets
 
 
-def loss_epilogue_packed(desc_fields: tuple, rgb_all, n_col_rays: int, n_ev: int, col_gt, evs_gt, pow_rgb=None, pow_evs=None, w31=None):
+def loss_epilogue_packed(desc_fields: tuple, rgb_all, n_col_rays: int, n_ev: int, col_gt, evs_gt, pow_rgb=None, pow_evs=None, w31=None,
+                         mlp_rgb=(), mlp_evs=()):
     """``loss_epilogue`` for the bundles of one packed pass, given as row blocks [colour | previous | next] of ONE render."""
     c = lambda t: _c(t.float()) if t is not None else None
     return _LossEpiloguePackedFn.apply(tuple(desc_fields), c(rgb_all), int(n_col_rays), int(n_ev), c(col_gt),
-                                       c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31)
+                                       c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31,
+                                       len(mlp_rgb), *mlp_rgb, *mlp_evs)
 
 
-def loss_epilogue(desc_fields: tuple, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb=None, pow_evs=None, w31=None):
+def loss_epilogue(desc_fields: tuple, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb=None, pow_evs=None, w31=None,
+                  mlp_rgb=(), mlp_evs=()):
     """Routing + intensity mappers + rgb MSE + log-intensity event MSE in one launch (lse_loss_epilogue_fwd).
     ``desc_fields`` = (rgb_mapped, rgb_mapper, evs_mapper, ev_one_dim, deblur_group, evs_loss_weight).
-    Returns (rgb_loss, event_loss) as 0-dim tensors."""
+    ``mlp_rgb`` / ``mlp_evs``: the eight parameters (module order) of an MLP mapper on the colour / event side (kinds LSE_MAP_MLP,
+    LSE_MAP_RGB_MLP; R:lse_nerf/intensity_mappers.py:28-62).  Returns (rgb_loss, event_loss) as 0-dim tensors."""
     c = lambda t: _c(t.float()) if t is not None else None
     return _LossEpilogueFn.apply(tuple(desc_fields), c(col_rgb), c(col_gt), c(prev_rgb), c(next_rgb),
-                                 c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31)
+                                 c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31,
+                                 len(mlp_rgb), *mlp_rgb, *mlp_evs)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Oracle: output routing (intensity mappers) and losses of LSENeRFModel -- R:lse_nerf/lsenerf.py:329-439,
-R:lse_nerf/intensity_mappers.py:64-94, R:lse_nerf/utils.py:12 (EPS).  TEST INFRASTRUCTURE, plain torch on CPU.
+R:lse_nerf/intensity_mappers.py:28-94, R:lse_nerf/utils.py:12 (EPS).  TEST INFRASTRUCTURE, plain torch on CPU.
 These are O(rays) element-wise ops; they define what "rendered RGB / log-intensity" means in the parity statement."""
 from __future__ import annotations
 
@@ -9,6 +9,20 @@ import torch
 import torch.nn.functional as F
 
 EPS = 1e-6
+
+
+def mlp_mapper(params):
+    """The "mlp" / "rgb_mlp" intensity mappers, R:lse_nerf/intensity_mappers.py:28-62: nerfstudio 0.3.2
+    ``MLP(in_dim, num_layers=4, layer_width=16, out_dim, activation=ReLU, out_activation=Sigmoid, implementation="torch")`` =
+    Linear(in,16) -> ReLU -> Linear(16,16) -> ReLU -> Linear(16,16) -> ReLU -> Linear(16,out) -> Sigmoid, applied to the last axis.
+    ``params`` = [W0, b0, W1, b1, W2, b2, W3, b3] in nn.Linear layout ([out, in]).  (The reference fits it to the identity at
+    construction, :8-26; the fit is host-side set-up, not part of the path.)"""
+    def apply(x):
+        for l in range(4):
+            x = x @ params[2 * l].T + params[2 * l + 1]
+            x = torch.relu(x) if l < 3 else torch.sigmoid(x)
+        return x
+    return apply
 
 
 def to_gray(x):

@@ -214,12 +214,59 @@ def make_config1():
          depth=out["depth"].numpy(), counts=out["num_samples_per_ray"].numpy().astype(np.int32))
 
 
+def epilogue_mlp_inputs():
+    """Inputs of the loss-epilogue fixture: co_map routing, "rgb_mlp" on the colour side, ThreeToOne + "mlp" on the event side
+    (R:lse_nerf/lsenerf.py:350-363, R:lse_nerf/intensity_mappers.py:28-62).  The mappers' parameters are nn.Linear's default draw
+    (uniform +-1/sqrt(fan_in)), NOT the identity fit of :8-26 -- that fit is host-side set-up, and an unfitted mapper exercises both
+    sides of every ReLU."""
+    g = gen(SEED + 7)
+    n_col, n_ev = 301, 130
+    rad = {k: torch.rand(n, 3, generator=g) * 1.2 - 0.02 for k, n in (("col", n_col), ("prev", n_ev), ("next", n_ev))}
+    rad["prev"][:3] = 0.0                                      # below the 1e-5 clamp
+    col_gt, evs_gt = torch.rand(n_col, 3, generator=g), (torch.rand(n_ev, 1, generator=g) - 0.5) * 0.4
+    w31 = torch.tensor([[0.2, 0.5, 0.3]])
+
+    def mlp(in_dim):
+        dims = [in_dim, 16, 16, 16, in_dim]
+        out = []
+        for l in range(4):
+            k = 1.0 / dims[l] ** 0.5
+            out += [(torch.rand(dims[l + 1], dims[l], generator=g) * 2 - 1) * k, (torch.rand(dims[l + 1], generator=g) * 2 - 1) * k]
+        return out
+    return rad, col_gt, evs_gt, w31, mlp(3), mlp(1)
+
+
+def make_epilogue():
+    from oracle.losses import loss_dict, mlp_mapper, route_outputs
+    rad, col_gt, evs_gt, w31, p_rgb, p_evs = epilogue_mlp_inputs()
+    leaf = lambda t: t.clone().requires_grad_(True)
+    rad_l = {k: leaf(v) for k, v in rad.items()}
+    w31_l, prgb_l, pevs_l = leaf(w31), [leaf(p) for p in p_rgb], [leaf(p) for p in p_evs]
+    kw = dict(training=True, use_mapping=True, map_mode="co_map", rgb_loss_type="linspace", rgb_mapper=mlp_mapper(prgb_l),
+              evs_mapper=mlp_mapper(pevs_l), three_to_one_w=w31_l)
+    routed = [route_outputs(rad_l[k], ev_out=(k != "col"), **kw) for k in ("col", "prev", "next")]
+    ld = loss_dict(routed[0], routed[1], routed[2], col_gt, evs_gt, use_mapping=True, evs_loss_weight=1.0)
+    (ld["rgb_loss"] * 1.3 + ld["event_loss"] * 0.6).backward()
+    arrs = dict(col=rad["col"].numpy(), prev=rad["prev"].numpy(), next=rad["next"].numpy(), col_gt=col_gt.numpy(), evs_gt=evs_gt.numpy(),
+                w31=w31.numpy(), loss_weights=np.float32([1.3, 0.6]), rgb_loss=np.float32(float(ld["rgb_loss"].detach())),
+                event_loss=np.float32(float(ld["event_loss"].detach())), d_col=rad_l["col"].grad.numpy(), d_prev=rad_l["prev"].grad.numpy(),
+                d_next=rad_l["next"].grad.numpy(), d_w31=w31_l.grad.numpy())
+    for side, ps, pl in (("rgb", p_rgb, prgb_l), ("evs", p_evs, pevs_l)):
+        for i, (p, l) in enumerate(zip(ps, pl)):
+            arrs[f"{side}_mlp_p{i}"] = p.numpy()
+            arrs[f"{side}_mlp_d{i}"] = l.grad.numpy()
+    save("loss_epilogue_co_map_mlp", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if "--only-big-hash" in sys.argv:          # (round 5: the 4096-point fixtures were added without rewriting the older files)
         make_hash_big()
+    elif "--only-epilogue" in sys.argv:        # (round 5, ABI 6: likewise)
+        make_epilogue()
     else:
         make_hash(); make_hash_big(); make_mlp(); make_sh(); make_traverse(); make_volrend(); make_grid_update(); make_config1()
+        make_epilogue()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f"{f:40s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KB")

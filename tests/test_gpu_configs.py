@@ -153,19 +153,33 @@ def test_config2_3_rgb_plus_events(emb_type, generator):
     assert rel_l2(hin[0][0].grad, cin[0][0].grad) < TOL_GRAD and rel_l2(hin[1][1].grad, cin[1][1].grad) < TOL_GRAD
 
 
-@pytest.mark.parametrize("case", ["co_map_powpow_learned", "evs_rgb_gt_gray", "rgb_evs_powpow", "plain_rgb_key", "deblur_co_map"])
-def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case):
+@pytest.mark.parametrize("case", ["co_map_powpow_learned", "evs_rgb_gt_gray", "rgb_evs_powpow", "plain_rgb_key", "deblur_co_map",
+                                  "co_map_rgb_mlp_mlp_learned", "rgb_evs_rgb_mlp", "deblur_evs_rgb_rgb_mlp_gray",
+                                  "co_map_powpow_rgb_mlp_events"])
+def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch):
     """lse_loss_epilogue_fwd / _bwd (one launch each way) against (i) the model's own torch routing + losses and (ii) the
     oracle's restatement (oracle/losses.py), values and every gradient: rendered radiance of the three bundles, powpow
-    coefficients, ThreeToOne weights -- over the map modes / mappers / one-dim choices of R:lse_nerf/lsenerf.py:329-439."""
+    coefficients, ThreeToOne weights, the 593 / 659 parameters of the MLP mappers (R:lse_nerf/intensity_mappers.py:28-62; their
+    weight gradients are summed on the f32 matrix core, csrc/epilogue.hip) -- over the map modes / mappers / one-dim choices of
+    R:lse_nerf/lsenerf.py:329-439."""
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig
-    from oracle.losses import loss_dict, route_outputs
+    from lsenerf_amd import model as M
+    from oracle.losses import loss_dict, mlp_mapper, route_outputs
+    monkeypatch.setattr(M.MLP_Mapper, "init_steps", 60)          # a partly fitted mapper: far from the identity, ReLUs on both sides
+    monkeypatch.setattr(M.RGB_MLP_Mapper, "init_steps", 60)
     kw = {"co_map_powpow_learned": dict(use_mapping=True, mapping_method="powpow", map_mode="co_map", evs_mapping_method="powpow", ev_one_dim="learned"),
           "evs_rgb_gt_gray": dict(use_mapping=True, mapping_method="gt", map_mode="evs_rgb", ev_one_dim="gt"),
           "rgb_evs_powpow": dict(use_mapping=True, mapping_method="powpow", map_mode="rgb_evs", ev_one_dim=False),
           "plain_rgb_key": dict(use_mapping=False, ev_one_dim=False, evs_loss_weight=0.7),
           "deblur_co_map": dict(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="gt",
-                                ev_one_dim="learned", rgb_loss_type="deblur")}[case]
+                                ev_one_dim="learned", rgb_loss_type="deblur"),
+          "co_map_rgb_mlp_mlp_learned": dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="co_map", evs_mapping_method="mlp",
+                                             ev_one_dim="learned"),
+          "rgb_evs_rgb_mlp": dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="rgb_evs", ev_one_dim=False),
+          "deblur_evs_rgb_rgb_mlp_gray": dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="evs_rgb", ev_one_dim="gt",
+                                              rgb_loss_type="deblur"),
+          "co_map_powpow_rgb_mlp_events": dict(use_mapping=True, mapping_method="powpow", map_mode="co_map",
+                                               evs_mapping_method="rgb_mlp", ev_one_dim=False)}[case]
     torch.manual_seed(0)
     cfg = LSENeRFModelConfig(grid_levels=1, grid_resolution=16, num_levels=4, log2_hashmap_size=12, **kw)
     m = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4).cuda().train()
@@ -209,9 +223,18 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case):
     lc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
     mapper = {"identity": (lambda x: x), "gt": (lambda x: x ** (1 / 2.4)), "powpow": None}
     method = cfg.mapping_method if cfg.use_mapping else "identity"        # (the config's default "mlp" is only read with use_mapping)
-    rgb_mapper = (lambda x: x ** pw["rgb"]) if method == "powpow" else mapper[method]
+    omlp = {}                                                             # the oracle's copies of the MLP mappers' parameters
+    for side, mod in (("rgb", getattr(m, "rgb_mapper", None)), ("evs", m.evs_mapper)):
+        if isinstance(mod, (M.MLP_Mapper, M.RGB_MLP_Mapper)):
+            omlp[side] = [p.detach().cpu().clone().requires_grad_(True) for p in mod.parameters()]
+    if method in ("mlp", "rgb_mlp"):
+        rgb_mapper = mlp_mapper(omlp["rgb"])
+    else:
+        rgb_mapper = (lambda x: x ** pw["rgb"]) if method == "powpow" else mapper[method]
     evs_mapper = None
-    if cfg.evs_mapping_method is not None:
+    if cfg.evs_mapping_method in ("mlp", "rgb_mlp"):
+        evs_mapper = mlp_mapper(omlp["evs"])
+    elif cfg.evs_mapping_method is not None:
         evs_mapper = (lambda x: x ** pw["evs"]) if cfg.evs_mapping_method == "powpow" else mapper[cfg.evs_mapping_method]
     gray_w = torch.log(torch.tensor([[0.2989, 0.5870, 0.1140]]))        # softmax(log w) == w: ToGrayGT through the same formula
     rkw = dict(training=True, use_mapping=cfg.use_mapping, map_mode=cfg.map_mode, rgb_loss_type=cfg.rgb_loss_type,
@@ -237,6 +260,11 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case):
         assert nmax_err(fused_param_grads["rgb_mapper.pow_coeff"], pw["rgb"].grad, 1e-6) < 1e-4
     if tw is not None:
         assert nmax_err(fused_param_grads["rgb_to_one.weights"], tw.grad, 1e-6) < 1e-4
+    for side, plist in omlp.items():                      # every layer of an MLP mapper against the oracle's autograd
+        names = [f"{side}_mapper.mlp.layers.{i}.{k}" for i in range(4) for k in ("weight", "bias")]
+        assert any(float(p.grad.abs().max()) > 0 for p in plist if p.grad is not None), side
+        for n, p in zip(names, plist):
+            assert p.grad is not None and nmax_err(fused_param_grads[n], p.grad, 1e-6) < 1e-4, n
 
 
 def test_config4_badnerf_deblur_pose_gradients():

@@ -22,12 +22,12 @@ def _every_stream_mismatch_counts():
     torch.set_warn_always(before)
 
 
-def _setup(ray_grads):
+def _setup(ray_grads, mappers=("identity", "powpow")):
     from lsenerf_amd import LSENeRFModel, LSENeRFModelConfig, RayBundle
     from lsenerf_amd.optim import FlatAdam, FlatParams
     torch.manual_seed(96)
-    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, use_mapping=True, mapping_method="identity",
-                             map_mode="co_map", evs_mapping_method="powpow")
+    cfg = LSENeRFModelConfig(grid_levels=2, grid_resolution=32, log2_hashmap_size=15, use_mapping=True, mapping_method=mappers[0],
+                             map_mode="co_map", evs_mapping_method=mappers[1])
     models, opts = [], []
     base = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 16)
     with torch.no_grad():
@@ -69,11 +69,16 @@ def _eager_step(m, opt, bundles, batch, jit, ray_grads):
     return {k: float(v) for k, v in losses.items()}, grad, bs
 
 
-@pytest.mark.parametrize("ray_grads", [False, True])
-def test_graphed_step_equals_eager_step(ray_grads):
-    from lsenerf_amd import ops
+@pytest.mark.parametrize("ray_grads,mappers", [(False, ("identity", "powpow")), (True, ("identity", "powpow")), (True, ("rgb_mlp", "mlp"))])
+def test_graphed_step_equals_eager_step(ray_grads, mappers, monkeypatch):
+    """(The third case trains the two MLP intensity mappers of R:lse_nerf/intensity_mappers.py:28-62 inside the captured step: their
+    1252 parameters are views of the flat buffer and the fused epilogue adds their gradients straight into the flat gradient.)"""
+    from lsenerf_amd import model as M, ops
     from lsenerf_amd.graph import GraphedTrainStep
-    (m_e, m_g), (o_e, o_g), batch_of = _setup(ray_grads)
+    monkeypatch.setattr(M.MLP_Mapper, "init_steps", 100)
+    monkeypatch.setattr(M.RGB_MLP_Mapper, "init_steps", 100)
+    (m_e, m_g), (o_e, o_g), batch_of = _setup(ray_grads, mappers)
+    assert m_g._epilogue_desc() is not None                       # the fused epilogue, not the torch route
     b0, batch0, jit0 = batch_of(50)
     step = GraphedTrainStep(m_g, o_g, *b0, batch0, ray_grads=ray_grads, jitter="input")
     assert o_g.step_count == 0 and torch.equal(o_g.flat.data, o_e.flat.data)        # building the graph trains nothing

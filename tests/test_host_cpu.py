@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"liblse_hip.so does not export {n}"
     # and the binding covers exactly the header (no stale or missing signatures)
     assert set(_lib.SIGNATURES) | {"lse_abi_version", "lse_last_error", "lse_hash_bwd_default_opts", "lse_hash_bwd_workspace_bytes"} == set(names)
-    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 5
+    assert lib.lse_abi_version() == _lib.LSE_ABI_VERSION == 6
 
 
 def test_the_shipped_library_has_no_state_to_set():
@@ -174,7 +174,9 @@ def test_model_wiring_and_param_groups():
 def test_mlp_intensity_mappers_are_identity_initialised(monkeypatch):
     """R:lse_nerf/intensity_mappers.py:8-63, 93-97: "mlp" (1 -> 16 -> 16 -> 16 -> 1) and "rgb_mlp" (3 -> ... -> 3), ReLU hidden
     layers, sigmoid output, fitted to the identity on [0, 1] at construction; selectable through mapping_method /
-    evs_mapping_method like the closed-form mappers, routed by the torch path (the fused epilogue declines them)."""
+    evs_mapping_method like the closed-form mappers, and -- since ABI 6 -- taken by the fused epilogue wherever the reference's own
+    nn.Linear accepts the channel count (a one-channel "mlp" on three channels raises there: such a plan stays on the torch route,
+    which raises the same error)."""
     import lsenerf_amd as la
     from lsenerf_amd import model as M
     assert set(M.MAPPERS_DICT) == {"mlp", "rgb_mlp", "gt", "identity", "powpow"}
@@ -193,10 +195,25 @@ def test_mlp_intensity_mappers_are_identity_initialised(monkeypatch):
     n_map = sum(p.numel() for p in m.rgb_mapper.parameters()) + sum(p.numel() for p in m.evs_mapper.parameters())
     assert n_map == (3 * 16 + 16 + 2 * (16 * 16 + 16) + 16 * 3 + 3) + (1 * 16 + 16 + 2 * (16 * 16 + 16) + 16 + 1)
     assert sum(p.numel() for p in m.get_param_groups()["fields"]) >= n_map        # trained with the field (R:lsenerf.py:237-243)
-    assert m._epilogue_desc() is None                                              # -> torch routing
+    from lsenerf_amd import _lib
+    fields, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs = m._epilogue_desc()           # -> the fused epilogue's MLP kernels
+    assert fields[:4] == (1, _lib.LSE_MAP_RGB_MLP, _lib.LSE_MAP_MLP, _lib.LSE_ONE_DIM_LEARNED) and pow_rgb is None and pow_evs is None
+    assert [tuple(p.shape) for p in mlp_rgb] == [(16, 3), (16,), (16, 16), (16,), (16, 16), (16,), (3, 16), (3,)]
+    assert [tuple(p.shape) for p in mlp_evs] == [(16, 1), (16,), (16, 16), (16,), (16, 16), (16,), (1, 16), (1,)]
+    assert all(a is b for a, b in zip(mlp_rgb, m.rgb_mapper.parameters())) and all(a is b for a, b in zip(mlp_evs, m.evs_mapper.parameters()))
     m.train()
     routed = m.route_outputs({"rgb": torch.rand(5, 3)}, None, ev_out=True)
     assert routed["rgb"].shape == (5, 3) and routed["ev_out"].shape == (5, 1)
+    # channel counts the first nn.Linear does not take: the plan keeps the torch route (and fails there like the reference)
+    for bad in (dict(mapping_method="mlp", map_mode="co_map", evs_mapping_method="gt", ev_one_dim="learned"),       # mlp on rgb
+                dict(mapping_method="identity", map_mode="co_map", evs_mapping_method="mlp", ev_one_dim=False),       # mlp on 3 event channels
+                dict(mapping_method="identity", map_mode="co_map", evs_mapping_method="rgb_mlp", ev_one_dim="gt")):  # rgb_mlp on 1
+        mb = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, **bad), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4)
+        assert mb._epilogue_desc() is None, bad
+    ok = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="rgb_mlp", map_mode="rgb_evs", ev_one_dim=False),
+                         torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4)
+    f2 = ok._epilogue_desc()
+    assert f2[0][:4] == (0, _lib.LSE_MAP_IDENTITY, _lib.LSE_MAP_RGB_MLP, _lib.LSE_ONE_DIM_NONE) and f2[4] == () and len(f2[5]) == 8
 
 
 def test_flat_params_and_adam_schedule_cpu():

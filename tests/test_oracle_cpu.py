@@ -343,3 +343,41 @@ def test_fma_contraction_changes_few_sample_intervals():
     assert golden_frac < 2e-5
     for name, (rays, sym, allk) in res.items():
         assert allk > 300_000 and sym / allk < 2e-5, (name, rays, sym, allk)
+
+
+def test_golden_loss_epilogue_with_mlp_mappers():
+    """The oracle's routing + MLP intensity mappers + losses against the committed fixture, and the mapper itself against an
+    independent formulation: torch's own nn.Sequential(Linear, ReLU, ..., Sigmoid) carrying the same parameters
+    (R:lse_nerf/intensity_mappers.py:28-62 builds exactly that through nerfstudio's MLP)."""
+    from oracle.losses import loss_dict, mlp_mapper, route_outputs
+    z = gold("loss_epilogue_co_map_mlp")
+    rad, col_gt, evs_gt, w31, p_rgb, p_evs = mg.epilogue_mlp_inputs()
+    for k in ("col", "prev", "next"):
+        assert np.array_equal(rad[k].numpy(), z[k])
+    for side, ps in (("rgb", p_rgb), ("evs", p_evs)):
+        assert all(np.array_equal(p.numpy(), z[f"{side}_mlp_p{i}"]) for i, p in enumerate(ps))
+        in_dim = ps[0].shape[1]
+        seq = torch.nn.Sequential(torch.nn.Linear(in_dim, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                  torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, in_dim), torch.nn.Sigmoid())
+        with torch.no_grad():
+            for l in range(4):
+                seq[2 * l].weight.copy_(ps[2 * l]); seq[2 * l].bias.copy_(ps[2 * l + 1])
+            x = torch.rand(257, in_dim, generator=mg.gen(5))
+            y = mlp_mapper(ps)(x)
+            assert y.shape == x.shape and float((y - seq(x)).abs().max()) < 1e-6 and float(y.std()) > 1e-3
+    leaf = lambda t: t.clone().requires_grad_(True)
+    rl, wl, prl, pel = {k: leaf(v) for k, v in rad.items()}, leaf(w31), [leaf(p) for p in p_rgb], [leaf(p) for p in p_evs]
+    kw = dict(training=True, use_mapping=True, map_mode="co_map", rgb_loss_type="linspace", rgb_mapper=mlp_mapper(prl),
+              evs_mapper=mlp_mapper(pel), three_to_one_w=wl)
+    routed = [route_outputs(rl[k], ev_out=(k != "col"), **kw) for k in ("col", "prev", "next")]
+    assert routed[1]["ev_out"].shape == (130, 1) and routed[0]["rgb"].shape == (301, 3)
+    ld = loss_dict(routed[0], routed[1], routed[2], col_gt, evs_gt, use_mapping=True)
+    (ld["rgb_loss"] * float(z["loss_weights"][0]) + ld["event_loss"] * float(z["loss_weights"][1])).backward()
+    assert abs(float(ld["rgb_loss"].detach()) - float(z["rgb_loss"])) < 1e-6 and abs(float(ld["event_loss"].detach()) - float(z["event_loss"])) < 1e-6
+    for k in ("col", "prev", "next"):
+        assert np.allclose(rl[k].grad.numpy(), z["d_" + k], rtol=1e-5, atol=1e-9), k
+    assert float(rl["prev"].grad[:3].abs().max()) == 0.0
+    assert np.allclose(wl.grad.numpy(), z["d_w31"], rtol=1e-4, atol=1e-8)
+    for side, pl in (("rgb", prl), ("evs", pel)):
+        for i, p in enumerate(pl):
+            assert np.allclose(p.grad.numpy(), z[f"{side}_mlp_d{i}"], rtol=1e-4, atol=1e-8), (side, i)
