@@ -759,7 +759,7 @@ def main():
         dom_ms = dom_ms_all[dom]
         achieved = HASH_BYTES_PER_SAMPLE * n_samples / (dom_ms * 1e-3) / 1e9
         b_step = n_samples * BYTES_PER_SAMPLE_STEP + 8 * 4 * flat.numel
-        traffic, sq_busy, stale = None, None, None
+        traffic, sq_busy, stale, sent_requests = None, None, None, None
         try:   # committed PMC summary of the same kernels (bench.py cannot run rocprofv3 on itself); see profiles/pmc_traffic.json.
             # Each group of counters is stamped with a digest of the kernel sources it was measured on (lsenerf_amd/provenance.py);
             # numbers from other sources than this tree's are NOT reported: null fields + "traffic_stale": true
@@ -769,6 +769,7 @@ def main():
             stale = {"hash": not provenance.counters_current(pmc, "hash"), "mlp": not provenance.counters_current(pmc, "mlp")}
             if not stale["hash"]:
                 traffic = pmc.get(dom, {}).get("bytes")
+                sent_requests = pmc.get("lse_hash_bwd", {}).get("atomic_requests")      # TCC_EA0_ATOMIC_sum per launch, same workload
             if not stale["mlp"]:
                 sq_busy = pmc.get("matrix_core_busy")
         except OSError:
@@ -790,8 +791,16 @@ def main():
             atomic = {"bound": "memory-side float atomics (requests of <= 64 B)", "request_floor_per_launch": req,
                       "requests_per_sample": req / n_samples, "peak_requests_per_s": 21e9,
                       "achieved_requests_per_s": req / (dom_ms * 1e-3), "frac": req / (dom_ms * 1e-3) / 21e9,
-                      "note": "floor = distinct 64-B table lines per 64-sample wave window, all 16 levels; the kernel sends 12 - 15 % "
-                              "more (cache collisions; profiles/r03_hash_bwd_memory_side_requests.txt)"}
+                      # what the kernel SENDS (committed rocprofv3 --pmc TCC_EA0_ATOMIC_sum pass of this workload on this tree's
+                      # kernel sources, null when the tree has moved on): the memory side is busy with these, not with the floor
+                      "sent_requests_per_launch": sent_requests,
+                      "sent_over_floor": (sent_requests / req) if sent_requests else None,
+                      "sent_requests_per_s": (sent_requests / (dom_ms * 1e-3)) if sent_requests else None,
+                      "sent_frac": (sent_requests / (dom_ms * 1e-3) / 21e9) if sent_requests else None,
+                      "note": "floor = distinct 64-B table lines per 64-sample wave window, all 16 levels; `frac` prices the FLOOR against "
+                              "the request rate (useful requests per second), `sent_frac` the requests the kernel actually sends "
+                              "(utilisation of the memory-side atomic units; the cache-free kernel saturates them at 20.5 G/s, "
+                              "profiles/r05_hash_bwd_ablation.txt)"}
         line = {
             "metric": "train-step rays/sec (4096-ray x 1024-sample batch)", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "backend": (tdist.get_backend() if tdist.is_initialized() else None),

@@ -12,8 +12,9 @@ timeout -k 10 600 python bench.py > $OUT/bench.log 2>&1; rc=$?; echo "bench rc=$
 if [ $rc -ne 0 ]; then exit $rc; fi
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-context --no-atomic-floor > $OUT/rocprof.log 2>&1; rc=$?
 echo "rocprof rc=$rc"; find $OUT/prof -name "*kernel_stats*" | head
-# HBM traffic counters: separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only
-for C in FETCH_SIZE WRITE_SIZE; do
+# HBM traffic counters: separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only; TCC_EA0_ATOMIC_sum = the
+# memory-side float-atomic REQUESTS the hash backward actually sends (priced against the request rate in bench.py's roofline.atomic)
+for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
   timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-context --no-atomic-floor > $OUT/pmc_$C.log 2>&1; rc=$?
   echo "pmc $C rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 done
