@@ -3,9 +3,12 @@
 TAG=${1:-r}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout -k 10 700 python -m pytest tests -m gpu -q --timeout 240 "$@" > $OUT/pytest.log 2>&1; rc=$?
-echo "pytest rc=$rc"; tail -4 $OUT/pytest.log
-if [ $rc -ge 124 ]; then echo "pytest killed; stopping"; exit $rc; fi
+if [ -z "$SKIP_PYTEST" ]; then
+  # unbuffered + verbose + faulthandler: a test that hangs is named in the log (a buffered -q log of a killed run is empty)
+  PYTHONUNBUFFERED=1 timeout -k 10 700 python -u -m pytest tests -m gpu -v --timeout 240 -o faulthandler_timeout=200 "$@" > $OUT/pytest.log 2>&1; rc=$?
+  echo "pytest rc=$rc"; tail -4 $OUT/pytest.log
+  if [ $rc -ge 124 ]; then echo "pytest killed; stopping"; exit $rc; fi
+fi
 timeout -k 10 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; rc=$?; echo "smoke rc=$rc"; tail -2 $OUT/smoke.log
 if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 600 python bench.py > $OUT/bench.log 2>&1; rc=$?; echo "bench rc=$rc"; tail -3 $OUT/bench.log | cut -c1-1800
