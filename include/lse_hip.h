@@ -366,7 +366,9 @@ int lse_occ_binarize(const float *occs, int64_t n, const float *d_threshold, uin
  *   cameras of a pixel, R:lse_nerf/lsenerf.py:365-370);  max(., 1e-5);  rgb_loss = mean (v - col_gt)^2.
  * Event bundles (prev, next):  c = max(rgb, 1e-5);  ev_one_dim != NONE: m_evs(sum_k w_k c_k) with w = softmax(w31)
  *   (ThreeToOne, LEARNED) or the gray vector (GRAY);  NONE: gray(m_evs(c));  L = log(. + 1e-6);
- *   event_loss = evs_loss_weight * mean (L_next - L_prev - evs_gt)^2          (log_loss).
+ *   event_loss = evs_loss_weight * mean (L_next - L_prev - evs_gt)^2          (log_loss, R:lse_nerf/lsenerf.py:392-399), or with
+ *   event_loss_kind = LSE_EVLOSS_ENERF_NORM (enerf_norm_loss, :406-419; ABI 6):  d_r = L_next - L_prev,  c_r = evs_gt[r] / e_thresh[r],
+ *   event_loss = evs_loss_weight * mean (d_r / (||d||_2 + 1e-6) - c_r / (||c||_2 + 1e-6))^2, norms over the event rays, c constant.
  * m = identity | x^(1/2.4) ("gt") | x^p ("powpow", p = *pow_rgb / *pow_evs, learnable) | "mlp" | "rgb_mlp" (ABI 6): the
  *   identity-initialised nerfstudio MLP(in, num_layers = 4, layer_width = 16, out = in, ReLU, out_activation = Sigmoid) of
  *   R:lse_nerf/intensity_mappers.py:28-62 -- "mlp" maps ONE channel (in = 1: the event side behind ev_one_dim; on three channels
@@ -390,6 +392,8 @@ typedef struct lse_mapper_mlp {
 #define LSE_ONE_DIM_NONE 0
 #define LSE_ONE_DIM_LEARNED 1
 #define LSE_ONE_DIM_GRAY 2
+#define LSE_EVLOSS_LOG 0
+#define LSE_EVLOSS_ENERF_NORM 1
 typedef struct lse_epilogue_desc {
     int32_t rgb_mapped;      /* 0: the colour loss sees the raw render; 1: m_rgb(max(rgb, 1e-5)) */
     int32_t rgb_mapper;      /* LSE_MAP_* */
@@ -397,19 +401,20 @@ typedef struct lse_epilogue_desc {
     int32_t ev_one_dim;      /* LSE_ONE_DIM_* */
     int32_t deblur_group;    /* 1, or 4 for rgb_loss_type == "deblur" */
     float evs_loss_weight;
+    int32_t event_loss_kind; /* LSE_EVLOSS_* */
 } lse_epilogue_desc;
 /* losses[2] = (rgb_loss, event_loss); a bundle whose pointer is NULL contributes 0.  Deterministic (no atomics). */
 /* mlp_rgb / mlp_evs: parameters of the colour-side / event-side mapper when its kind is LSE_MAP_MLP / LSE_MAP_RGB_MLP (else ignored,
- * NULL allowed). */
+ * NULL allowed).  e_thresh [n_ev]: the per-ray event threshold of LSE_EVLOSS_ENERF_NORM (NULL = 1; ignored by log_loss). */
 int lse_loss_epilogue_fwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
-                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
+                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, const float *e_thresh, int32_t n_ev,
                           const float *pow_rgb, const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb,
                           const lse_mapper_mlp *mlp_evs, float *losses, lse_stream_t stream);
 /* g_rgb_loss / g_event_loss: device scalars, the upstream gradients of the two losses (NULL = 0).  d_col [n_col*deblur_group,3], d_prev / d_next [n_ev,3]
  * (each nullable) are overwritten; d_scalars[5] = (d pow_rgb, d pow_evs, d w31[3]) is overwritten; the gradients of an MLP mapper's
  * parameters are accumulated into mlp_*->dw / db. */
 int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
-                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev,
+                          const float *prev_rgb, const float *next_rgb, const float *evs_gt, const float *e_thresh, int32_t n_ev,
                           const float *pow_rgb, const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb,
                           const lse_mapper_mlp *mlp_evs, const float *g_rgb_loss, const float *g_event_loss, float *d_col,
                           float *d_prev, float *d_next, float *d_scalars, lse_stream_t stream);

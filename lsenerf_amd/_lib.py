@@ -38,7 +38,7 @@ class HashBwdOpts(Structure):
 
 class EpilogueDesc(Structure):
     _fields_ = [("rgb_mapped", c_int32), ("rgb_mapper", c_int32), ("evs_mapper", c_int32), ("ev_one_dim", c_int32),
-                ("deblur_group", c_int32), ("evs_loss_weight", c_float)]
+                ("deblur_group", c_int32), ("evs_loss_weight", c_float), ("event_loss_kind", c_int32)]
 
 
 LSE_MAP_IDENTITY, LSE_MAP_GT, LSE_MAP_POWPOW, LSE_MAP_MLP, LSE_MAP_RGB_MLP = 1, 2, 3, 4, 5
@@ -50,6 +50,7 @@ class MapperMlp(Structure):
 
 
 LSE_ONE_DIM_NONE, LSE_ONE_DIM_LEARNED, LSE_ONE_DIM_GRAY = 0, 1, 2
+LSE_EVLOSS_LOG, LSE_EVLOSS_ENERF_NORM = 0, 1
 
 
 class MlpDesc(Structure):
@@ -98,8 +99,8 @@ SIGNATURES = {
     "lse_volrend_depth_fwd": [P, P, P, P, I32, P, I32, P, P, P, P, P, P, P, P],
     "lse_render_weight_fwd": [P, P, P, P, I32, P, P, P, P],
     "lse_render_weight_bwd": [P, P, P, P, I32, P, P, P, P],
-    "lse_loss_epilogue_fwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp), P, P],
-    "lse_loss_epilogue_bwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp),
+    "lse_loss_epilogue_fwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp), P, P],
+    "lse_loss_epilogue_bwd": [POINTER(EpilogueDesc), P, P, I32, P, P, P, P, I32, P, P, P, POINTER(MapperMlp), POINTER(MapperMlp),
                               P, P, P, P, P, P, P],
     "lse_occ_update_cells": [P, P, P, I64, F32, P, P],
     "lse_occ_binarize": [P, I64, P, P, P],

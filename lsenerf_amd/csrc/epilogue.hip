@@ -5,6 +5,7 @@
 //   MLP intensity mappers ("mlp" 1 -> 16 -> 16 -> 16 -> 1, "rgb_mlp" 3 -> 3)   R:lse_nerf/intensity_mappers.py:28-62
 //   deblur mean over the 4 virtual cameras of a pixel                         R:lse_nerf/lsenerf.py:365-370
 //   rgb MSE and the log-intensity event MSE (log_loss, EPS 1e-6)              R:lse_nerf/lsenerf.py:392-439, R:lse_nerf/utils.py:12
+//   enerf_norm_loss (both sides of the event MSE divided by their 2-norm over the rays)   R:lse_nerf/lsenerf.py:406-419
 //
 // The work is a few thousand rays x a handful of flops, so the design target is launch count, not bandwidth: one
 // 1024-thread workgroup walks all rays, reduces the losses (and, in the backward, the three scalar-parameter gradients)
@@ -31,13 +32,14 @@ struct EpiArgs {
     const float *prev_rgb;    // [n_ev, 3] (nullable: no event loss)
     const float *next_rgb;    // [n_ev, 3]
     const float *evs_gt;      // [n_ev]
+    const float *e_thresh;    // [n_ev] per-ray event threshold (enerf_norm_loss only; nullable = 1)
     const float *pow_rgb;     // [1] powpow coefficient of the rgb mapper (mapper kind 3)
     const float *pow_evs;     // [1] powpow coefficient of the event mapper
     const float *w31;         // [3] ThreeToOne raw weights (softmax inside)
     lse_mapper_mlp mlp_rgb;   // parameters (+ gradient destinations) of an MLP mapper on the colour side (kind LSE_MAP_RGB_MLP)
     lse_mapper_mlp mlp_evs;   // ... on the event side (LSE_MAP_MLP behind ev_one_dim, LSE_MAP_RGB_MLP otherwise)
     int n_col, n_ev;
-    bool uses_mlp;            // an MLP mapper is active: the epilogue_mlp_* kernel pair
+    bool uses_mlp;            // an MLP mapper or enerf_norm_loss is active: the epilogue_mlp_* kernel pair
     // forward outputs
     float *losses;            // [2] = (rgb_loss, event_loss)
     // backward
@@ -515,6 +517,23 @@ __device__ __forceinline__ float ev_any_fwd(const lse_epilogue_desc &d, const fl
     return kGray[0] * y[0] + kGray[1] * y[1] + kGray[2] * y[2];
 }
 
+// d_r = log(intensity_next + EPS) - log(intensity_prev + EPS) of event ray r, and its target c_r (evs_gt, over the event threshold
+// for enerf_norm_loss: R:lse_nerf/lsenerf.py:416)
+__device__ __forceinline__ float ev_delta(const EpiArgs &a, int r, const float (&w)[3], float p, const float *img)
+{
+    const float *pp = a.prev_rgb + 3 * (int64_t)r, *pn = a.next_rgb + 3 * (int64_t)r;
+    const float xp[3] = {pp[0], pp[1], pp[2]}, xn[3] = {pn[0], pn[1], pn[2]};
+    float c[3], s;
+    const float lp = logf(ev_any_fwd(a.d, xp, w, p, img, c, s) + kLogEps);
+    const float ln = logf(ev_any_fwd(a.d, xn, w, p, img, c, s) + kLogEps);
+    return ln - lp;
+}
+__device__ __forceinline__ float ev_target(const EpiArgs &a, int r)
+{
+    if (a.d.event_loss_kind == LSE_EVLOSS_ENERF_NORM) return a.evs_gt[r] / (a.e_thresh ? a.e_thresh[r] : 1.f);
+    return a.evs_gt[r];
+}
+
 __global__ __launch_bounds__(1024) void epilogue_mlp_fwd_kernel(EpiArgs a)
 {
     __shared__ float smem[2 * 16];
@@ -550,13 +569,20 @@ __global__ __launch_bounds__(1024) void epilogue_mlp_fwd_kernel(EpiArgs a)
     if (a.prev_rgb) {
         float w[3];
         one_dim_weights(a, w);
+        float inv_nd = 1.f, inv_ne = 1.f;
+        if (a.d.event_loss_kind == LSE_EVLOSS_ENERF_NORM) {
+            float s2[2] = {0.f, 0.f};
+            for (int r = threadIdx.x; r < a.n_ev; r += blockDim.x) {
+                const float dl = ev_delta(a, r, w, p_evs, img_evs), ce = ev_target(a, r);
+                s2[0] += dl * dl;
+                s2[1] += ce * ce;
+            }
+            block_sum<2>(s2, smem);
+            inv_nd = 1.f / (sqrtf(s2[0]) + kLogEps);
+            inv_ne = 1.f / (sqrtf(s2[1]) + kLogEps);
+        }
         for (int r = threadIdx.x; r < a.n_ev; r += blockDim.x) {
-            const float *pp = a.prev_rgb + 3 * (int64_t)r, *pn = a.next_rgb + 3 * (int64_t)r;
-            const float xp[3] = {pp[0], pp[1], pp[2]}, xn[3] = {pn[0], pn[1], pn[2]};
-            float c[3], s;
-            const float lp = logf(ev_any_fwd(a.d, xp, w, p_evs, img_evs, c, s) + kLogEps);
-            const float ln = logf(ev_any_fwd(a.d, xn, w, p_evs, img_evs, c, s) + kLogEps);
-            const float e = (ln - lp) - a.evs_gt[r];
+            const float e = ev_delta(a, r, w, p_evs, img_evs) * inv_nd - ev_target(a, r) * inv_ne;
             acc[1] += e * e;
         }
     }
@@ -685,6 +711,28 @@ __global__ __launch_bounds__(kMlpBwdThreads) void epilogue_mlp_bwd_kernel(EpiArg
         float w[3], dw[3] = {0.f, 0.f, 0.f};
         one_dim_weights(a, w);
         const float k = g_evs * a.d.evs_loss_weight * 2.f / (float)a.n_ev;
+        // enerf_norm_loss: e_r = d_r / nd - c_r / ne with nd = ||d|| + EPS;  dL/dd_k = k (e_k / nd - T d_k / (nd^2 ||d||)),  T = sum_r e_r d_r
+        float inv_nd = 1.f, inv_ne = 1.f, t_over = 0.f;
+        const bool enerf = a.d.event_loss_kind == LSE_EVLOSS_ENERF_NORM;
+        if (enerf) {
+            float s2[2] = {0.f, 0.f};
+            for (int r = threadIdx.x; r < a.n_ev; r += blockDim.x) {
+                const float dl = ev_delta(a, r, w, p_evs, img_evs), ce = ev_target(a, r);
+                s2[0] += dl * dl;
+                s2[1] += ce * ce;
+            }
+            block_sum<2>(s2, smem);
+            const float norm = sqrtf(s2[0]);
+            inv_nd = 1.f / (norm + kLogEps);
+            inv_ne = 1.f / (sqrtf(s2[1]) + kLogEps);
+            float t[1] = {0.f};
+            for (int r = threadIdx.x; r < a.n_ev; r += blockDim.x) {
+                const float dl = ev_delta(a, r, w, p_evs, img_evs);
+                t[0] += (dl * inv_nd - ev_target(a, r) * inv_ne) * dl;
+            }
+            block_sum<1>(t, smem);
+            t_over = norm > 0.f ? t[0] * inv_nd * inv_nd / norm : 0.f;      // (torch: the norm's subgradient at 0 is 0)
+        }
         for (int base = 0; base < a.n_ev; base += blockDim.x) {
             const int r = base + threadIdx.x;
             const bool live = r < a.n_ev;
@@ -694,10 +742,8 @@ __global__ __launch_bounds__(kMlpBwdThreads) void epilogue_mlp_bwd_kernel(EpiArg
                 const float *pp = a.prev_rgb + 3 * (int64_t)r, *pn = a.next_rgb + 3 * (int64_t)r;
                 xp[0] = pp[0]; xp[1] = pp[1]; xp[2] = pp[2];
                 xn[0] = pn[0]; xn[1] = pn[1]; xn[2] = pn[2];
-                float c[3], s;
-                const float lp = logf(ev_any_fwd(a.d, xp, w, p_evs, img_evs, c, s) + kLogEps);
-                const float ln = logf(ev_any_fwd(a.d, xn, w, p_evs, img_evs, c, s) + kLogEps);
-                dd = k * ((ln - lp) - a.evs_gt[r]);
+                const float dl = ev_delta(a, r, w, p_evs, img_evs);
+                dd = enerf ? k * ((dl * inv_nd - ev_target(a, r) * inv_ne) * inv_nd - t_over * dl) : k * (dl - a.evs_gt[r]);
             }
             float dn[3], dp[3];
             ev_any_bwd(a.d, xn, w, p_evs, img_evs, dd, live, dn, sc[1], dw, stage, acc);
@@ -744,13 +790,14 @@ int check_desc(const lse_epilogue_desc *d, const char *who)
     LSE_REQUIRE(d->evs_mapper != LSE_MAP_MLP || d->ev_one_dim != LSE_ONE_DIM_NONE, "%s: the one-channel \"mlp\" event mapper needs ev_one_dim", who);
     LSE_REQUIRE(d->evs_mapper != LSE_MAP_RGB_MLP || d->ev_one_dim == LSE_ONE_DIM_NONE, "%s: the three-channel \"rgb_mlp\" event mapper excludes ev_one_dim", who);
     LSE_REQUIRE(d->deblur_group >= 1 && d->deblur_group <= 16, "%s: deblur_group %d out of range", who, d->deblur_group);
+    LSE_REQUIRE(d->event_loss_kind == LSE_EVLOSS_LOG || d->event_loss_kind == LSE_EVLOSS_ENERF_NORM, "%s: bad event_loss_kind %d", who, d->event_loss_kind);
     return LSE_OK;
 }
 
 int fill(EpiArgs &a, const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt, int32_t n_col,
-         const float *prev_rgb, const float *next_rgb, const float *evs_gt, int32_t n_ev, const float *pow_rgb,
-         const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb, const lse_mapper_mlp *mlp_evs, bool backward,
-         const char *who)
+         const float *prev_rgb, const float *next_rgb, const float *evs_gt, const float *e_thresh, int32_t n_ev,
+         const float *pow_rgb, const float *pow_evs, const float *w31, const lse_mapper_mlp *mlp_rgb, const lse_mapper_mlp *mlp_evs,
+         bool backward, const char *who)
 {
     int rc = check_desc(desc, who);
     if (rc) return rc;
@@ -761,7 +808,7 @@ int fill(EpiArgs &a, const lse_epilogue_desc *desc, const float *col_rgb, const 
     LSE_REQUIRE(desc->evs_mapper != LSE_MAP_POWPOW || !prev_rgb || pow_evs, "%s: powpow event mapper without coefficient", who);
     LSE_REQUIRE(desc->ev_one_dim != LSE_ONE_DIM_LEARNED || !prev_rgb || w31, "%s: learned ThreeToOne without weights", who);
     a.d = *desc;
-    a.col_rgb = col_rgb; a.col_gt = col_gt; a.prev_rgb = prev_rgb; a.next_rgb = next_rgb; a.evs_gt = evs_gt;
+    a.col_rgb = col_rgb; a.col_gt = col_gt; a.prev_rgb = prev_rgb; a.next_rgb = next_rgb; a.evs_gt = evs_gt; a.e_thresh = e_thresh;
     a.pow_rgb = pow_rgb; a.pow_evs = pow_evs; a.w31 = w31; a.n_col = n_col; a.n_ev = n_ev;
     const bool use_rgb = col_rgb && desc->rgb_mapped && desc->rgb_mapper == LSE_MAP_RGB_MLP;
     const bool use_evs = prev_rgb && desc->evs_mapper >= LSE_MAP_MLP;
@@ -778,7 +825,8 @@ int fill(EpiArgs &a, const lse_epilogue_desc *desc, const float *col_rgb, const 
         LSE_REQUIRE(!backward || n_grad == 0 || n_grad == 8, "%s: MLP %s mapper: gradient destinations come all eight or none", who, sd.side);
         *sd.dst = *sd.src;
     }
-    a.uses_mlp = use_rgb || use_evs;
+    // the second kernel pair serves every mapper kind and both event losses; the first one the closed-form mappers with log_loss
+    a.uses_mlp = use_rgb || use_evs || (prev_rgb && desc->event_loss_kind == LSE_EVLOSS_ENERF_NORM);
     return LSE_OK;
 }
 
@@ -786,12 +834,12 @@ int fill(EpiArgs &a, const lse_epilogue_desc *desc, const float *col_rgb, const 
 
 extern "C" int lse_loss_epilogue_fwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt,
                                      int32_t n_col, const float *prev_rgb, const float *next_rgb, const float *evs_gt,
-                                     int32_t n_ev, const float *pow_rgb, const float *pow_evs, const float *w31,
+                                     const float *e_thresh, int32_t n_ev, const float *pow_rgb, const float *pow_evs, const float *w31,
                                      const lse_mapper_mlp *mlp_rgb, const lse_mapper_mlp *mlp_evs, float *losses,
                                      lse_stream_t stream)
 {
     EpiArgs a{};
-    int rc = fill(a, desc, col_rgb, col_gt, n_col, prev_rgb, next_rgb, evs_gt, n_ev, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs, false,
+    int rc = fill(a, desc, col_rgb, col_gt, n_col, prev_rgb, next_rgb, evs_gt, e_thresh, n_ev, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs, false,
                   "lse_loss_epilogue_fwd");
     if (rc) return rc;
     LSE_REQUIRE(losses, "lse_loss_epilogue_fwd: null losses");
@@ -803,13 +851,13 @@ extern "C" int lse_loss_epilogue_fwd(const lse_epilogue_desc *desc, const float 
 
 extern "C" int lse_loss_epilogue_bwd(const lse_epilogue_desc *desc, const float *col_rgb, const float *col_gt,
                                      int32_t n_col, const float *prev_rgb, const float *next_rgb, const float *evs_gt,
-                                     int32_t n_ev, const float *pow_rgb, const float *pow_evs, const float *w31,
+                                     const float *e_thresh, int32_t n_ev, const float *pow_rgb, const float *pow_evs, const float *w31,
                                      const lse_mapper_mlp *mlp_rgb, const lse_mapper_mlp *mlp_evs, const float *g_rgb_loss,
                                      const float *g_event_loss, float *d_col, float *d_prev, float *d_next, float *d_scalars,
                                      lse_stream_t stream)
 {
     EpiArgs a{};
-    int rc = fill(a, desc, col_rgb, col_gt, n_col, prev_rgb, next_rgb, evs_gt, n_ev, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs, true,
+    int rc = fill(a, desc, col_rgb, col_gt, n_col, prev_rgb, next_rgb, evs_gt, e_thresh, n_ev, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs, true,
                   "lse_loss_epilogue_bwd");
     if (rc) return rc;
     LSE_REQUIRE(!prev_rgb || !d_prev == !d_next, "lse_loss_epilogue_bwd: d_prev and d_next come together");

@@ -692,14 +692,15 @@ class LSENeRFModel(nn.Module):
     # -- fused training epilogue -----------------------------------------------------------------------------
     def _epilogue_desc(self) -> Optional[Tuple[tuple, Optional[Tensor], Optional[Tensor], Optional[Tensor], tuple, tuple]]:
         """(descriptor fields, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs) for ops.loss_epilogue, or None when the configuration needs
-        the torch route (enerf_norm_loss, an unrouted map_mode, the event loss reading a deblur-averaged "rgb", or an MLP mapper on a
-        channel count its first nn.Linear does not take -- the reference raises there, and so does the torch route).  ``mlp_*``: the
+        the torch route (an unrouted map_mode, the event loss reading a deblur-averaged "rgb", or an MLP mapper on a channel count
+        its first nn.Linear does not take -- the reference raises there, and so does the torch route).  ``mlp_*``: the
         eight parameters of an MLP mapper on that side in module order (R:lse_nerf/intensity_mappers.py:28-62), () otherwise."""
         from . import _lib
         cfg, plan = self.config, self._plan()
         kinds = {IdentityMapper: _lib.LSE_MAP_IDENTITY, GT_Mapper: _lib.LSE_MAP_GT, Powpow: _lib.LSE_MAP_POWPOW,
                  MLP_Mapper: _lib.LSE_MAP_MLP, RGB_MLP_Mapper: _lib.LSE_MAP_RGB_MLP, type(None): _lib.LSE_MAP_IDENTITY}
-        if plan["unrouted"] or cfg.event_loss_type.lower() != "log_loss" or type(plan["rgb_mapper"]) not in kinds \
+        ev_loss = {"log_loss": _lib.LSE_EVLOSS_LOG, "enerf_norm_loss": _lib.LSE_EVLOSS_ENERF_NORM}.get(cfg.event_loss_type.lower())
+        if plan["unrouted"] or ev_loss is None or type(plan["rgb_mapper"]) not in kinds \
                 or type(plan["ev_mapper"]) not in kinds or (plan["ev_key"] == "rgb" and plan["deblur_group"] > 1):
             return None
         od = plan["ev_one_dim"]
@@ -709,12 +710,20 @@ class LSENeRFModel(nn.Module):
         if rgb_kind == _lib.LSE_MAP_MLP or (evs_kind == _lib.LSE_MAP_MLP and not one_channel) \
                 or (evs_kind == _lib.LSE_MAP_RGB_MLP and one_channel):
             return None           # nn.Linear(1, 16) on three channels / nn.Linear(3, 16) on one
-        fields = (int(plan["rgb_mapper"] is not None), rgb_kind, evs_kind, one_dim, plan["deblur_group"], float(cfg.evs_loss_weight))
+        fields = (int(plan["rgb_mapper"] is not None), rgb_kind, evs_kind, one_dim, plan["deblur_group"], float(cfg.evs_loss_weight),
+                  ev_loss)
         coeff = lambda m: m.pow_coeff if isinstance(m, Powpow) else None
         layers = lambda m: tuple(p for layer in m.mlp.layers for p in (layer.weight, layer.bias)) \
             if isinstance(m, (MLP_Mapper, RGB_MLP_Mapper)) else ()
         return (fields, coeff(plan["rgb_mapper"]), coeff(plan["ev_mapper"]), (od.weights if isinstance(od, ThreeToOne) else None),
                 layers(plan["rgb_mapper"]), layers(plan["ev_mapper"]))
+
+    @staticmethod
+    def _e_thresh(batch, fields):
+        """evs_batch["e_thresh"] when the event loss divides by it (enerf_norm_loss, R:lse_nerf/lsenerf.py:416: a KeyError when the
+        batch does not carry it, like the reference's)."""
+        from . import _lib
+        return batch["evs_batch"]["e_thresh"] if fields[6] == _lib.LSE_EVLOSS_ENERF_NORM else None
 
     def fused_loss_dict(self, raw_outputs: Dict[str, Optional[Dict[str, Tensor]]], batch,
                         packed_rgb: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -733,7 +742,8 @@ class LSENeRFModel(nn.Module):
             n_ev = prev["rgb"].shape[0] if prev is not None else 0
             rgb_loss, event_loss = ops.loss_epilogue_packed(
                 fields, packed_rgb, n_col, n_ev, batch["col_batch"]["image"] if col is not None else None,
-                batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs)
+                batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs,
+                e_thresh=self._e_thresh(batch, fields) if prev is not None else None)
             losses = {}
             if col is not None:
                 losses["rgb_loss"] = rgb_loss
@@ -748,7 +758,8 @@ class LSENeRFModel(nn.Module):
         rgb_loss, event_loss = ops.loss_epilogue(
             fields, col["rgb"] if col is not None else None, batch["col_batch"]["image"] if col is not None else None,
             prev["rgb"] if prev is not None else None, nxt["rgb"] if nxt is not None else None,
-            batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs)
+            batch["evs_batch"]["image"] if prev is not None else None, pow_rgb, pow_evs, w31, mlp_rgb, mlp_evs,
+            e_thresh=self._e_thresh(batch, fields) if prev is not None else None)
         losses = {}
         if col is not None:
             losses["rgb_loss"] = rgb_loss

@@ -1047,7 +1047,8 @@ def _byref(struct):
 
 class _LossEpilogueFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, desc_fields, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, n_mlp_rgb=0, *mlp_params):
+    def forward(ctx, desc_fields, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, e_thresh=None, n_mlp_rgb=0,
+                *mlp_params):
         dev = (col_rgb if col_rgb is not None else prev_rgb).device
         desc = _lib.EpilogueDesc(*desc_fields)
         group = desc.deblur_group
@@ -1058,17 +1059,18 @@ class _LossEpilogueFn(torch.autograd.Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
-                  n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _f32(e_thresh, "e_thresh", True), n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True),
+                  _f32(w31, "w31", True),
                   _byref(_mapper_mlp_struct(mlp_params[:n_mlp_rgb])), _byref(_mapper_mlp_struct(mlp_params[n_mlp_rgb:])),
                   ctypes.c_void_p(losses.data_ptr()), _stream())
-        ctx.save_for_backward(col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, *mlp_params)
+        ctx.save_for_backward(col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, e_thresh, *mlp_params)
         ctx.desc_fields, ctx.n_col, ctx.n_ev, ctx.n_mlp_rgb = desc_fields, n_col, n_ev, n_mlp_rgb
         ctx.set_materialize_grads(False)
         return losses[0], losses[1]
 
     @staticmethod
     def backward(ctx, g_rgb, g_evs):
-        col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, *mlp_params = ctx.saved_tensors
+        col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb, pow_evs, w31, e_thresh, *mlp_params = ctx.saved_tensors
         dev = (col_rgb if col_rgb is not None else prev_rgb).device
         desc = _lib.EpilogueDesc(*ctx.desc_fields)
         mlp_bufs, mlp_rets = _mapper_mlp_grads(mlp_params)
@@ -1081,11 +1083,12 @@ class _LossEpilogueFn(torch.autograd.Function):
         d_sc = torch.empty(5, dtype=torch.float32, device=dev)
         _lib.call("lse_loss_epilogue_bwd", ctypes.byref(desc), _f32(col_rgb, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   ctx.n_col, _f32(prev_rgb, "prev_rgb", True), _f32(next_rgb, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
-                  ctx.n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _f32(e_thresh, "e_thresh", True), ctx.n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True),
+                  _f32(w31, "w31", True),
                   _byref(_mapper_mlp_struct(mlp_params[:k], mlp_bufs[:k])), _byref(_mapper_mlp_struct(mlp_params[k:], mlp_bufs[k:])),
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(d_col, "d_col", True),
                   _f32(d_prev, "d_prev", True), _f32(d_next, "d_next", True), ctypes.c_void_p(d_sc.data_ptr()), _stream())
-        return (None, d_col, None, d_prev, d_next, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None,) + mlp_rets
+        return (None, d_col, None, d_prev, d_next, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None, None) + mlp_rets
 
 
 def _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31):
@@ -1118,7 +1121,8 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
     3-bundle step, tools/graph_timeline.py)."""
 
     @staticmethod
-    def forward(ctx, desc_fields, rgb_all, n_col_rays, n_ev, col_gt, evs_gt, pow_rgb, pow_evs, w31, n_mlp_rgb=0, *mlp_params):
+    def forward(ctx, desc_fields, rgb_all, n_col_rays, n_ev, col_gt, evs_gt, pow_rgb, pow_evs, w31, e_thresh=None, n_mlp_rgb=0,
+                *mlp_params):
         dev = rgb_all.device
         desc = _lib.EpilogueDesc(*desc_fields)
         group = desc.deblur_group
@@ -1133,17 +1137,18 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
         losses = torch.empty(2, dtype=torch.float32, device=dev)
         _lib.call("lse_loss_epilogue_fwd", ctypes.byref(desc), _f32(col, "col_rgb", True), _f32(col_gt, "col_gt", True),
                   n_col_rays // group, _f32(prev, "prev_rgb", True), _f32(nxt, "next_rgb", True), _f32(evs_gt, "evs_gt", True),
-                  n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
+                  _f32(e_thresh, "e_thresh", True), n_ev, _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True),
+                  _f32(w31, "w31", True),
                   _byref(_mapper_mlp_struct(mlp_params[:n_mlp_rgb])), _byref(_mapper_mlp_struct(mlp_params[n_mlp_rgb:])),
                   ctypes.c_void_p(losses.data_ptr()), _stream())
-        ctx.save_for_backward(rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, *mlp_params)
+        ctx.save_for_backward(rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, e_thresh, *mlp_params)
         ctx.desc_fields, ctx.n_col_rays, ctx.n_ev, ctx.n_mlp_rgb = desc_fields, n_col_rays, n_ev, n_mlp_rgb
         ctx.set_materialize_grads(False)
         return losses[0], losses[1]
 
     @staticmethod
     def backward(ctx, g_rgb, g_evs):
-        rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, *mlp_params = ctx.saved_tensors
+        rgb_all, col_gt, evs_gt, pow_rgb, pow_evs, w31, e_thresh, *mlp_params = ctx.saved_tensors
         dev = rgb_all.device
         desc = _lib.EpilogueDesc(*ctx.desc_fields)
         mlp_bufs, mlp_rets = _mapper_mlp_grads(mlp_params)
@@ -1155,33 +1160,49 @@ class _LossEpiloguePackedFn(torch.autograd.Function):
         part = lambda t, a, b: (t[a:b] if b > a else None)
         _lib.call("lse_loss_epilogue_bwd", ctypes.byref(desc), _f32(part(rgb_all, 0, n0), "col_rgb", True), _f32(col_gt, "col_gt", True),
                   n0 // desc.deblur_group, _f32(part(rgb_all, n0, n0 + ne), "prev_rgb", True),
-                  _f32(part(rgb_all, n0 + ne, n0 + 2 * ne), "next_rgb", True), _f32(evs_gt, "evs_gt", True), ne,
+                  _f32(part(rgb_all, n0 + ne, n0 + 2 * ne), "next_rgb", True), _f32(evs_gt, "evs_gt", True),
+                  _f32(e_thresh, "e_thresh", True), ne,
                   _f32(pow_rgb, "pow_rgb", True), _f32(pow_evs, "pow_evs", True), _f32(w31, "w31", True),
                   _byref(_mapper_mlp_struct(mlp_params[:k], mlp_bufs[:k])), _byref(_mapper_mlp_struct(mlp_params[k:], mlp_bufs[k:])),
                   _f32(g_rgb, "g_rgb_loss", True), _f32(g_evs, "g_event_loss", True), _f32(part(d_all, 0, n0), "d_col", True),
                   _f32(part(d_all, n0, n0 + ne), "d_prev", True), _f32(part(d_all, n0 + ne, n0 + 2 * ne), "d_next", True),
                   ctypes.c_void_p((d_sc := torch.empty(5, dtype=torch.float32, device=dev)).data_ptr()), _stream())
-        return (None, d_all, None, None, None, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None,) + mlp_rets
+        return (None, d_all, None, None, None, None) + _scalar_param_grads(d_sc, pow_rgb, pow_evs, w31) + (None, None) + mlp_rets
+
+
+def _event_thresholds(e_thresh, n_ev: int, like):
+    """evs_batch["e_thresh"] (a number, a 1-element tensor or one value per event ray, R:lse_nerf/lse_pixel_sampler.py:36-37) as the
+    [n_ev] float vector of lse_loss_epilogue_*; None stays None (= 1)."""
+    if e_thresh is None or like is None:
+        return None
+    t = torch.as_tensor(e_thresh, dtype=torch.float32, device=like.device).reshape(-1)
+    if t.numel() == 1:
+        t = t.expand(n_ev)
+    if t.numel() != n_ev:
+        raise ValueError(f"e_thresh holds {t.numel()} values for {n_ev} event rays")
+    return t.contiguous()
 
 
 def loss_epilogue_packed(desc_fields: tuple, rgb_all, n_col_rays: int, n_ev: int, col_gt, evs_gt, pow_rgb=None, pow_evs=None, w31=None,
-                         mlp_rgb=(), mlp_evs=()):
+                         mlp_rgb=(), mlp_evs=(), e_thresh=None):
     """``loss_epilogue`` for the bundles of one packed pass, given as row blocks [colour | previous | next] of ONE render."""
     c = lambda t: _c(t.float()) if t is not None else None
     return _LossEpiloguePackedFn.apply(tuple(desc_fields), c(rgb_all), int(n_col_rays), int(n_ev), c(col_gt),
                                        c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31,
-                                       len(mlp_rgb), *mlp_rgb, *mlp_evs)
+                                       _event_thresholds(e_thresh, int(n_ev), evs_gt), len(mlp_rgb), *mlp_rgb, *mlp_evs)
 
 
 def loss_epilogue(desc_fields: tuple, col_rgb, col_gt, prev_rgb, next_rgb, evs_gt, pow_rgb=None, pow_evs=None, w31=None,
-                  mlp_rgb=(), mlp_evs=()):
+                  mlp_rgb=(), mlp_evs=(), e_thresh=None):
     """Routing + intensity mappers + rgb MSE + log-intensity event MSE in one launch (lse_loss_epilogue_fwd).
-    ``desc_fields`` = (rgb_mapped, rgb_mapper, evs_mapper, ev_one_dim, deblur_group, evs_loss_weight).
+    ``desc_fields`` = (rgb_mapped, rgb_mapper, evs_mapper, ev_one_dim, deblur_group, evs_loss_weight[, event_loss_kind]).
+    ``e_thresh``: evs_batch["e_thresh"] for event_loss_kind = LSE_EVLOSS_ENERF_NORM (R:lse_nerf/lsenerf.py:406-419).
     ``mlp_rgb`` / ``mlp_evs``: the eight parameters (module order) of an MLP mapper on the colour / event side (kinds LSE_MAP_MLP,
     LSE_MAP_RGB_MLP; R:lse_nerf/intensity_mappers.py:28-62).  Returns (rgb_loss, event_loss) as 0-dim tensors."""
     c = lambda t: _c(t.float()) if t is not None else None
     return _LossEpilogueFn.apply(tuple(desc_fields), c(col_rgb), c(col_gt), c(prev_rgb), c(next_rgb),
                                  c(evs_gt.reshape(-1)) if evs_gt is not None else None, pow_rgb, pow_evs, w31,
+                                 _event_thresholds(e_thresh, prev_rgb.shape[0] if prev_rgb is not None else 0, evs_gt),
                                  len(mlp_rgb), *mlp_rgb, *mlp_evs)
 
 

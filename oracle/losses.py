@@ -70,7 +70,21 @@ def log_loss(evs, prev_rad, next_rad):
     return F.mse_loss(torch.log(next_rad + EPS) - torch.log(prev_rad + EPS), evs)
 
 
-def loss_dict(col_out, prev_out, next_out, col_gt, evs_gt, *, use_mapping: bool, evs_loss_weight: float = 1.0):
+def enerf_norm_loss(evs, prev_rad, next_rad, e_thresh):
+    """R:lse_nerf/lsenerf.py:406-419: both sides of the event MSE divided by their 2-norm over the rays (dim 0); the event side is
+    first divided by the event threshold and carries no gradient."""
+    if prev_rad.shape[-1] != 1:
+        prev_rad, next_rad = to_gray(prev_rad), to_gray(next_rad)
+    delta_log = torch.log(next_rad + EPS) - torch.log(prev_rad + EPS)
+    log_norm = torch.linalg.norm(delta_log, dim=0, keepdim=True) + EPS
+    with torch.no_grad():
+        evs = evs / e_thresh
+        evs_norm = torch.linalg.norm(evs, dim=0, keepdim=True) + EPS
+    return F.mse_loss(delta_log / log_norm, evs / evs_norm)
+
+
+def loss_dict(col_out, prev_out, next_out, col_gt, evs_gt, *, use_mapping: bool, evs_loss_weight: float = 1.0,
+              event_loss: str = "log_loss", e_thresh=None):
     """R:lse_nerf/lsenerf.py:422-439."""
     out = {}
     if col_out is not None:
@@ -79,5 +93,5 @@ def loss_dict(col_out, prev_out, next_out, col_gt, evs_gt, *, use_mapping: bool,
         key = "ev_out" if use_mapping else "rgb"
         p, n = prev_out[key], next_out[key]
         evs = evs_gt if p.shape[-1] == 1 else torch.cat([evs_gt] * 3, -1)
-        out["event_loss"] = evs_loss_weight * log_loss(evs, p, n)
+        out["event_loss"] = evs_loss_weight * (log_loss(evs, p, n) if event_loss == "log_loss" else enerf_norm_loss(evs, p, n, e_thresh))
     return out

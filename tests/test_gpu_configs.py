@@ -155,7 +155,8 @@ def test_config2_3_rgb_plus_events(emb_type, generator):
 
 @pytest.mark.parametrize("case", ["co_map_powpow_learned", "evs_rgb_gt_gray", "rgb_evs_powpow", "plain_rgb_key", "deblur_co_map",
                                   "co_map_rgb_mlp_mlp_learned", "rgb_evs_rgb_mlp", "deblur_evs_rgb_rgb_mlp_gray",
-                                  "co_map_powpow_rgb_mlp_events"])
+                                  "co_map_powpow_rgb_mlp_events", "enerf_co_map_powpow_learned", "enerf_rgb_evs_gt",
+                                  "enerf_co_map_rgb_mlp_mlp_learned"])
 def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch):
     """lse_loss_epilogue_fwd / _bwd (one launch each way) against (i) the model's own torch routing + losses and (ii) the
     oracle's restatement (oracle/losses.py), values and every gradient: rendered radiance of the three bundles, powpow
@@ -179,7 +180,14 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch)
           "deblur_evs_rgb_rgb_mlp_gray": dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="evs_rgb", ev_one_dim="gt",
                                               rgb_loss_type="deblur"),
           "co_map_powpow_rgb_mlp_events": dict(use_mapping=True, mapping_method="powpow", map_mode="co_map",
-                                               evs_mapping_method="rgb_mlp", ev_one_dim=False)}[case]
+                                               evs_mapping_method="rgb_mlp", ev_one_dim=False),
+          # enerf_norm_loss (R:lse_nerf/lsenerf.py:406-419) inside the fused epilogue: closed-form and MLP mappers
+          "enerf_co_map_powpow_learned": dict(use_mapping=True, mapping_method="powpow", map_mode="co_map", evs_mapping_method="powpow",
+                                              ev_one_dim="learned", event_loss_type="enerf_norm_loss", evs_loss_weight=3.0),
+          "enerf_rgb_evs_gt": dict(use_mapping=True, mapping_method="gt", map_mode="rgb_evs", ev_one_dim=False,
+                                   event_loss_type="enerf_norm_loss"),
+          "enerf_co_map_rgb_mlp_mlp_learned": dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="co_map", evs_mapping_method="mlp",
+                                                   ev_one_dim="learned", event_loss_type="enerf_norm_loss")}[case]
     torch.manual_seed(0)
     cfg = LSENeRFModelConfig(grid_levels=1, grid_resolution=16, num_levels=4, log2_hashmap_size=12, **kw)
     m = LSENeRFModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4).cuda().train()
@@ -200,7 +208,8 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch)
         if cfg.ev_one_dim == "learned":
             m.rgb_to_one.weights.copy_(torch.tensor([[0.2, 0.5, 0.3]]))
     tw = torch.tensor([[0.2, 0.5, 0.3]], requires_grad=True) if cfg.ev_one_dim == "learned" else None
-    batch = {"col_batch": {"image": col_gt.cuda()}, "evs_batch": {"image": evs_gt.cuda()}}
+    e_thresh = 0.15 + 0.1 * torch.rand(n_ev, 1, generator=g)          # per event ray, R:lse_nerf/lse_pixel_sampler.py:36-37
+    batch = {"col_batch": {"image": col_gt.cuda()}, "evs_batch": {"image": evs_gt.cuda(), "e_thresh": e_thresh.cuda()}}
 
     def leaves():
         return {k: v.clone().cuda().requires_grad_(True) for k, v in raw.items()}
@@ -241,7 +250,8 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch)
                rgb_mapper=rgb_mapper, evs_mapper=evs_mapper,
                three_to_one_w=tw if cfg.ev_one_dim == "learned" else (gray_w if cfg.ev_one_dim == "gt" else None))
     oref = [route_outputs(lc[k], ev_out=(k != "col"), **rkw) for k in ("col", "prev", "next")]
-    rl = loss_dict(oref[0], oref[1], oref[2], col_gt, evs_gt, use_mapping=cfg.use_mapping, evs_loss_weight=cfg.evs_loss_weight)
+    rl = loss_dict(oref[0], oref[1], oref[2], col_gt, evs_gt, use_mapping=cfg.use_mapping, evs_loss_weight=cfg.evs_loss_weight,
+                   event_loss=cfg.event_loss_type, e_thresh=e_thresh)
     (rl["rgb_loss"] * 1.3 + rl["event_loss"] * 0.6).backward()
     for k in ("rgb_loss", "event_loss"):
         assert abs(float(fused[k]) - float(tl[k])) < 1e-5 * max(1.0, abs(float(tl[k]))), (k, float(fused[k]), float(tl[k]))
@@ -252,10 +262,14 @@ def test_fused_loss_epilogue_matches_torch_routing_and_oracle(case, monkeypatch)
     assert float(la["prev"].grad[:5].abs().max()) == 0.0
     torch_param_grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
     assert set(fused_param_grads) == set(torch_param_grads)
+    # enerf_norm_loss divides the log-intensity change by its own norm, and a powpow exponent on the one-channel event side only
+    # SCALES that change (log s^p = p log s): the loss does not depend on the exponent but for the two EPS terms, its gradient is a sum
+    # of cancelling O(1e-3) terms that ends at ~6e-6 -- compared on the scale of the summands there, not of the residue
+    floor_of = lambda n: 1e-4 if (cfg.event_loss_type == "enerf_norm_loss" and n == "evs_mapper.pow_coeff") else 1e-6
     for n, gten in fused_param_grads.items():
-        assert nmax_err(gten, torch_param_grads[n], 1e-6) < 1e-4, n
+        assert nmax_err(gten, torch_param_grads[n], floor_of(n)) < 1e-4, n
     if "evs" in pw:
-        assert nmax_err(fused_param_grads["evs_mapper.pow_coeff"], pw["evs"].grad, 1e-6) < 1e-4
+        assert nmax_err(fused_param_grads["evs_mapper.pow_coeff"], pw["evs"].grad, floor_of("evs_mapper.pow_coeff")) < 1e-4
     if "rgb" in pw and pw["rgb"].grad is not None:
         assert nmax_err(fused_param_grads["rgb_mapper.pow_coeff"], pw["rgb"].grad, 1e-6) < 1e-4
     if tw is not None:

@@ -8,7 +8,7 @@ match the stream of the node that produced the incoming gradient" -- is an ERROR
 occurrence counts.  Run as its own process: a regression may be a segfault.
 
 Cases: the cfg 2 and cfg 3 compositions at full size on the fused epilogue, and cfg 2 on the TORCH route of the loss
-(event_loss_type enerf_norm_loss: Powpow / ThreeToOne parameters consumed by plain torch ops), each with ray gradients."""
+(a mapper subclass the fused epilogue does not know: Powpow / ThreeToOne parameters consumed by plain torch ops), each with ray gradients."""
 import os, sys, warnings
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -19,9 +19,9 @@ from lsenerf_amd.graph import GraphedTrainStep
 for kind in ("cfg2", "cfg3", "cfg2_torch_route"):
     m, opt, bundles, batch, jit = _build(kind.split("_")[0])
     if kind.endswith("torch_route"):
-        m.config.event_loss_type = "enerf_norm_loss"
-        m.event_loss = m.log_losses_dict["enerf_norm_loss"]
-        batch["evs_batch"]["e_thresh"] = 0.2
+        # a mapper class the fused epilogue does not know (a user's subclass): the plan falls back to the torch routing, where the
+        # Powpow / ThreeToOne parameters are consumed by plain torch ops
+        m.evs_mapper.__class__ = type("UserPowpow", (type(m.evs_mapper),), {})
         assert m._epilogue_desc() is None, "expected the torch route of the loss"
     keep = []
     for _ in range(2):          # eager steps whose losses / outputs stay alive, on the default stream
