@@ -255,6 +255,19 @@ def make_epilogue():
         for i, (p, l) in enumerate(zip(ps, pl)):
             arrs[f"{side}_mlp_p{i}"] = p.numpy()
             arrs[f"{side}_mlp_d{i}"] = l.grad.numpy()
+    # the same inputs under enerf_norm_loss (R:lse_nerf/lsenerf.py:406-419) with a per-ray event threshold
+    e_thresh = 0.15 + 0.1 * torch.rand(rad["prev"].shape[0], 1, generator=gen(SEED + 8))
+    rad_e = {k: leaf(v) for k, v in rad.items()}
+    w31_e, prgb_e, pevs_e = leaf(w31), [leaf(p) for p in p_rgb], [leaf(p) for p in p_evs]
+    kw.update(rgb_mapper=mlp_mapper(prgb_e), evs_mapper=mlp_mapper(pevs_e), three_to_one_w=w31_e)
+    routed = [route_outputs(rad_e[k], ev_out=(k != "col"), **kw) for k in ("col", "prev", "next")]
+    le = loss_dict(routed[0], routed[1], routed[2], col_gt, evs_gt, use_mapping=True, evs_loss_weight=1.0, event_loss="enerf_norm_loss",
+                   e_thresh=e_thresh)
+    le["event_loss"].backward()
+    arrs.update(e_thresh=e_thresh.numpy(), enerf_event_loss=np.float32(float(le["event_loss"].detach())),
+                enerf_d_prev=rad_e["prev"].grad.numpy(), enerf_d_next=rad_e["next"].grad.numpy(), enerf_d_w31=w31_e.grad.numpy())
+    for i, l in enumerate(pevs_e):
+        arrs[f"enerf_evs_mlp_d{i}"] = l.grad.numpy()
     save("loss_epilogue_co_map_mlp", **arrs)
 
 

@@ -381,3 +381,13 @@ def test_golden_loss_epilogue_with_mlp_mappers():
     for side, pl in (("rgb", prl), ("evs", pel)):
         for i, p in enumerate(pl):
             assert np.allclose(p.grad.numpy(), z[f"{side}_mlp_d{i}"], rtol=1e-4, atol=1e-8), (side, i)
+    # the same inputs under enerf_norm_loss: the fixture, and the closed form of the loss written out independently
+    from oracle.losses import enerf_norm_loss
+    e_thr = torch.from_numpy(z["e_thresh"])
+    with torch.no_grad():
+        pe, ne = routed[1]["ev_out"], routed[2]["ev_out"]
+        got = float(enerf_norm_loss(evs_gt, pe, ne, e_thr))
+        d = (torch.log(ne + 1e-6) - torch.log(pe + 1e-6)).double()
+        c = (evs_gt / e_thr).double()
+        want = float(((d / (d.pow(2).sum().sqrt() + 1e-6) - c / (c.pow(2).sum().sqrt() + 1e-6)) ** 2).mean())
+    assert abs(got - want) < 1e-7 * max(1.0, want) and abs(got - float(z["enerf_event_loss"])) < 1e-7
