@@ -1175,7 +1175,9 @@ def _event_thresholds(e_thresh, n_ev: int, like):
     [n_ev] float vector of lse_loss_epilogue_*; None stays None (= 1)."""
     if e_thresh is None or like is None:
         return None
-    t = torch.as_tensor(e_thresh, dtype=torch.float32, device=like.device).reshape(-1)
+    if not torch.is_tensor(e_thresh):      # a number: a fill kernel (capturable), not a host-to-device copy
+        return torch.full((n_ev,), float(e_thresh), dtype=torch.float32, device=like.device)
+    t = e_thresh.to(device=like.device, dtype=torch.float32).reshape(-1)
     if t.numel() == 1:
         t = t.expand(n_ev)
     if t.numel() != n_ev:

@@ -458,3 +458,29 @@ def test_hash_bwd_hooks_belong_to_their_table_and_die_with_their_owner():
     del owner
     gc.collect()
     assert ops.get_hash_bwd_hook(t2, "split") is None and not ops._HASH_BWD_HOOKS
+
+
+def test_event_thresholds_of_the_fused_enerf_loss():
+    """evs_batch["e_thresh"] reaches lse_loss_epilogue_* as one float per event ray whatever form the data manager hands it in
+    (R:lse_nerf/lse_dataset.py:63 a 1-element tensor per image, R:lse_nerf/lse_pixel_sampler.py:36-37 indexed per ray); a wrong
+    length is an error, None stays None (= 1), and enerf_norm_loss configurations take the fused epilogue."""
+    import lsenerf_amd as la
+    from lsenerf_amd import _lib, ops
+    like = torch.zeros(5, 1)
+    assert ops._event_thresholds(None, 5, like) is None and ops._event_thresholds(0.2, 5, None) is None
+    assert torch.equal(ops._event_thresholds(0.25, 5, like), torch.full((5,), 0.25))
+    assert torch.equal(ops._event_thresholds(torch.tensor([0.5]), 5, like), torch.full((5,), 0.5))
+    per_ray = torch.arange(5.0).reshape(5, 1) + 1
+    out = ops._event_thresholds(per_ray, 5, like)
+    assert out.shape == (5,) and out.is_contiguous() and torch.equal(out, per_ray.reshape(-1))
+    with pytest.raises(ValueError, match="e_thresh"):
+        ops._event_thresholds(torch.ones(4), 5, like)
+    m = la.LSENeRFModel(la.LSENeRFModelConfig(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow",
+                                              event_loss_type="enerf_norm_loss"), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 4)
+    fields = m._epilogue_desc()[0]
+    assert len(fields) == 7 and fields[6] == _lib.LSE_EVLOSS_ENERF_NORM
+    assert m._e_thresh({"evs_batch": {"e_thresh": 0.2}}, fields) == 0.2
+    with pytest.raises(KeyError):
+        m._e_thresh({"evs_batch": {}}, fields)              # the reference's evs_batch["e_thresh"] (R:lse_nerf/lsenerf.py:416)
+    log_fields = fields[:6] + (_lib.LSE_EVLOSS_LOG,)
+    assert m._e_thresh({"evs_batch": {}}, log_fields) is None
