@@ -475,10 +475,11 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
 
 
 def test_hash_bwd_chunk_mapping_covers_every_sample_count():
-    """The default hash backward hands workgroup b the chunk (b % 8) * ceil(B / 8) + b / 8 of the B chunks the samples fill (every
-    XCD walks one contiguous eighth) and launches a multiple of 8 workgroups over the CAPACITY: sample counts around the chunk
-    (64) and 8-chunk borders, and device-side counts anywhere between 0 and the capacity, must each be covered exactly once --
-    checked against the oracle (host counts) and against the same call on the truncated arrays (device counts)."""
+    """The default hash backward hands workgroup b the position (b % 8) * ceil(B / 8) + b / 8 of the B positions the samples fill
+    (every XCD walks one contiguous eighth; a position = the 4 consecutive 64-sample chunks one wave walks) and launches a multiple
+    of 8 workgroups over the CAPACITY: sample counts around the chunk (64), position (256) and 8-position borders, and device-side
+    counts anywhere between 0 and the capacity, must each be covered exactly once -- checked against the oracle (host counts) and
+    against the same call on the truncated arrays (device counts)."""
     import ctypes
     from oracle import hashgrid as ohg
     from lsenerf_amd import _lib
@@ -487,11 +488,12 @@ def test_hash_bwd_chunk_mapping_covers_every_sample_count():
     meta = ops.make_grid_meta(n_levels=16, log2_hashmap_size=15)
     g = torch.Generator().manual_seed(12)
     table = (torch.rand(meta.n_params, generator=g) * 2 - 1) * 0.1
-    cap = 64 * 8 * 3 + 200
+    cap = 256 * 8 * 2 + 200
     x_all = _ray_coherent_points(4, (cap + 3) // 4, seed=5)[:cap].contiguous()
     w_all = torch.randn(cap, 32, generator=g)
     tg = table.cuda()
-    for n in (1, 63, 64, 65, 64 * 7 + 1, 64 * 8, 64 * 8 + 1, 64 * 9 - 1, 64 * 16 + 17, cap):
+    for n in (1, 63, 64, 65, 255, 256, 257, 64 * 7 + 1, 64 * 8, 64 * 8 + 1, 64 * 9 - 1, 64 * 16 + 17, 256 * 8 - 1, 256 * 8, 256 * 8 + 1,
+              256 * 9 + 65, cap):
         x, w = x_all[:n].contiguous(), w_all[:n].contiguous()
         tc = table.clone().requires_grad_(True)
         (ohg.hash_encode_tcnn(x, tc, meta_o) * w).sum().backward()
@@ -504,7 +506,8 @@ def test_hash_bwd_chunk_mapping_covers_every_sample_count():
     dy_cap = w_all.reshape(cap, 16, 2).permute(1, 0, 2).contiguous().cuda()
     desc = meta.desc()
     P = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
-    for n_dev in (0, 1, 64, 65, 64 * 8 - 1, 64 * 8, 64 * 8 + 1, 1000, cap - 1, cap, cap + 77):
+    for n_dev in (0, 1, 64, 65, 255, 256, 257, 64 * 8 - 1, 64 * 8, 64 * 8 + 1, 1000, 256 * 8 - 1, 256 * 8, 256 * 8 + 1, 256 * 11 + 3,
+                  cap - 1, cap, cap + 77):
         cnt = torch.tensor([n_dev], dtype=torch.int64, device="cuda")
         dt = torch.zeros_like(tg); dx = torch.full_like(xg, 7.0)
         _lib.call("lse_hash_bwd", ctypes.byref(desc), P(xg), P(dy_cap), P(tg), P(dt), P(dx), cap, P(cnt), ops._stream())
