@@ -787,10 +787,8 @@ __global__ __launch_bounds__(256) void hash_bwd_cached_kernel(GridParams g, cons
 // pair bucket takes an even-aligned pair of list positions (an absent sibling is an idle entry), so a line is never split.
 // kWaves: waves per workgroup.  Nothing below synchronises across waves (every wave owns its cache), so the workgroup size only sets
 // the granularity at which LDS is handed out: 4 x 512 slots = 80 KB -> 8 waves per CU; 2 x 384 slots = 30.5 KB -> 10 waves per CU.
-// kIters: consecutive 64-sample chunks a wave walks with ONE set-up of its cache (the 20 KB are cleared once: 72 DS wave-instructions;
-// every pass leaves the cache empty).
 template <bool WITH_DX, int kSlots, int kEntLog2, bool kPair = false, bool kFlush2 = false, bool kPrefetch = false, bool kAlign = false,
-          int kWaves = 4, int kIters = 1>
+          int kWaves = 4>
 __global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParams g, const float *__restrict__ x,
                                                               const float2 *__restrict__ dy,
                                                               const float2 *__restrict__ table,
@@ -831,13 +829,13 @@ __global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParam
     // identity mapping, for A/B.)
     int64_t wg = blockIdx.x;
     if (!(dbg & 32)) {
-        const int64_t positions = (n + (int64_t)kChunk * kWaves * kIters - 1) / ((int64_t)kChunk * kWaves * kIters);
+        const int64_t positions = (n + (int64_t)kChunk * kWaves - 1) / ((int64_t)kChunk * kWaves);
         const int64_t per_xcd = (positions + 7) >> 3;
         if ((wg >> 3) >= per_xcd) return;      // (the grid covers the capacity, rounded up to a multiple of 8)
         wg = (wg & 7) * per_xcd + (wg >> 3);
     }
-    const int64_t first_base = (wg * kWaves + wave) * (int64_t)kIters * kChunk;      // this wave's kIters consecutive chunks
-    if (first_base >= n) return;
+    const int64_t wave_base = (wg * kWaves + wave) * kChunk;
+    if (wave_base >= n) return;
     lds_u32 *key = (lds_u32 *)&s_key[wave][0];
     lds_f32 *val = (lds_f32 *)&s_val[wave][0];
     lds_u16 *list = (lds_u16 *)&s_list[wave][0];
@@ -849,9 +847,6 @@ __global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParam
     for (int s = lane; s < kSlots; s += 64) key[s] = kNoLine;
     for (int s = lane; s < kSlots * kPay; s += 64) val[s] = 0.f;
 
-    for (int iter = 0; iter < kIters; ++iter) {      // (the body below keeps its indentation: one chunk of 64 samples per trip)
-    const int64_t wave_base = first_base + (int64_t)iter * kChunk;
-    if (wave_base >= n) break;
     float px[kRounds][3], dacc[kRounds][3];
     int64_t si[kRounds];
     bool valid[kRounds];
@@ -1299,7 +1294,6 @@ __global__ __launch_bounds__(64 * kWaves) void hash_bwd_batched_kernel(GridParam
                 dx[si[r] * 3 + 2] = dacc[r][2];
             }
     }
-    }      // iter
 }
 
 
@@ -1607,7 +1601,7 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
 #endif
     LSE_REQUIRE(o.impl >= 0 && o.impl <= 2, "lse_hash_bwd: opts.impl must be 0, 1 or 2");
     LSE_REQUIRE(o.stage_max >= 0 && o.stage_max <= 64, "lse_hash_bwd: opts.stage_max must be in [0, 64]");
-    LSE_REQUIRE(o.gran >= 2 && o.gran <= 16, "lse_hash_bwd: opts.gran must be 2 .. 16");
+    LSE_REQUIRE(o.gran >= 2 && o.gran <= 13, "lse_hash_bwd: opts.gran must be 2 .. 13");
     LSE_REQUIRE(o.rounds == 16 || o.rounds == 32 || o.rounds == 64, "lse_hash_bwd: opts.rounds must be 16, 32 or 64");
     LSE_REQUIRE(o.few_runs >= 0 && o.few_runs <= 16, "lse_hash_bwd: opts.few_runs must be in [0, 16]");
     GridParams g;
@@ -1689,17 +1683,16 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         const float2 *dy2 = reinterpret_cast<const float2 *>(dy);
         const float2 *tb2 = reinterpret_cast<const float2 *>(tb);
         // (workgroups of WAVES waves with SLOTS cache slots per wave; nothing in the kernel synchronises across waves)
-#define LSE_HASH_BWD_LAUNCH(SLOTS, WAVES, ITERS)                                                                                       \
+#define LSE_HASH_BWD_LAUNCH(SLOTS, WAVES)                                                                                              \
         {                                                                                                                                 \
-            const int64_t per_wg = (int64_t)(WAVES) * 64 * (ITERS);                                                                       \
-            const int64_t bl = ((n + per_wg - 1) / per_wg + 7) / 8 * 8;      /* (chunk mapping: a multiple of 8) */                        \
+            const int64_t bl = ((n + (WAVES) * 64 - 1) / ((WAVES) * 64) + 7) / 8 * 8;      /* (chunk mapping: a multiple of 8) */          \
             LSE_REQUIRE(bl < (1ll << 31), "lse_hash_bwd: grid too large");                                                                \
-            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, SLOTS, 2, true, true, false, false, WAVES, ITERS>),                 \
-                                       dim3((unsigned)bl), dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs,  \
-                                       o.second_probe, o.stage_max, ws, n_dev);                                                          \
-            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, SLOTS, 2, true, true, false, false, WAVES, ITERS>),                   \
-                                    dim3((unsigned)bl), dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs,     \
-                                    o.second_probe, o.stage_max, ws, n_dev);                                                             \
+            if (dx) hipLaunchKernelGGL((hash_bwd_batched_kernel<true, SLOTS, 2, true, true, false, false, WAVES>), dim3((unsigned)bl),    \
+                                       dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe,       \
+                                       o.stage_max, ws, n_dev);                                                                          \
+            else hipLaunchKernelGGL((hash_bwd_batched_kernel<false, SLOTS, 2, true, true, false, false, WAVES>), dim3((unsigned)bl),      \
+                                    dim3(64 * (WAVES)), 0, st, g, x01, dy2, tb2, dtable, dx, n, dbg, o.few_runs, o.second_probe,          \
+                                    o.stage_max, ws, n_dev);                                                                             \
             return lse::check_launch("lse_hash_bwd");                                                                                     \
         }
 #ifdef LSE_DEV_KNOBS
@@ -1740,23 +1733,18 @@ extern "C" int lse_hash_bwd_ex(const lse_grid_desc *desc, const float *x01, cons
         }
         // between the two: smaller workgroups hand the LDS out in finer portions.  gran 9: 384 slots, two waves per workgroup (30.5 KB)
         // -> 10 waves per CU; gran 10: 448 slots, one wave per workgroup (17.6 KB) -> 9 waves per CU; gran 11: 384 slots, one wave; gran 12 / 13: 512 slots in workgroups of four (the shape until round 5) / two waves.
-        if (o.gran == 9) LSE_HASH_BWD_LAUNCH(384, 2, 1)
-        if (o.gran == 10) LSE_HASH_BWD_LAUNCH(448, 1, 1)
-        if (o.gran == 11) LSE_HASH_BWD_LAUNCH(384, 1, 1)
-        if (o.gran == 12) LSE_HASH_BWD_LAUNCH(512, 4, 1)
-        if (o.gran == 13) LSE_HASH_BWD_LAUNCH(512, 2, 1)
+        if (o.gran == 9) LSE_HASH_BWD_LAUNCH(384, 2)
+        if (o.gran == 10) LSE_HASH_BWD_LAUNCH(448, 1)
+        if (o.gran == 11) LSE_HASH_BWD_LAUNCH(384, 1)
+        if (o.gran == 12) LSE_HASH_BWD_LAUNCH(512, 4)
+        if (o.gran == 13) LSE_HASH_BWD_LAUNCH(512, 2)
 #endif
         // THE production kernel: paired 32-byte sectors, second-generation flush, 512 slots per wave, ONE wave per workgroup.  A
         // workgroup's LDS is released when its last wave retires, and waves differ in how many cache passes their samples need:
         // in workgroups of four (until round 5) a CU held 20 KB per early finisher idle.  One wave per workgroup: samples in the
         // contracted shell 2.53 -> 2.40 ms, headline, M-packed and the default configuration within +-1 %
         // (profiles/r05_hash_bwd_workgroup_size.txt).
-#ifdef LSE_DEV_KNOBS
-        if (o.gran == 14) LSE_HASH_BWD_LAUNCH(512, 1, 1)      // one chunk per workgroup (production until the second half of round 5)
-        if (o.gran == 15) LSE_HASH_BWD_LAUNCH(512, 1, 2)
-        if (o.gran == 16) LSE_HASH_BWD_LAUNCH(512, 1, 8)
-#endif
-        if (o.gran == 6) LSE_HASH_BWD_LAUNCH(512, 1, 4)
+        if (o.gran == 6) LSE_HASH_BWD_LAUNCH(512, 1)
 #undef LSE_HASH_BWD_LAUNCH
 #ifdef LSE_DEV_KNOBS
         if (o.gran == 4) {      // 32-byte slots paired by 64-byte line, flush list in slot order

@@ -475,9 +475,9 @@ def test_hash_bwd_metric_regime_every_kernel_variant_vs_oracle():
 
 
 def test_hash_bwd_chunk_mapping_covers_every_sample_count():
-    """The default hash backward hands workgroup b the position (b % 8) * ceil(B / 8) + b / 8 of the B positions the samples fill
-    (every XCD walks one contiguous eighth; a position = the 4 consecutive 64-sample chunks one wave walks) and launches a multiple
-    of 8 workgroups over the CAPACITY: sample counts around the chunk (64), position (256) and 8-position borders, and device-side
+    """The default hash backward hands workgroup b the chunk (b % 8) * ceil(B / 8) + b / 8 of the B chunks the samples fill (every
+    XCD walks one contiguous eighth) and launches a multiple of 8 workgroups over the CAPACITY: sample counts around the chunk
+    (64) and 8-chunk borders (and around 256 / 2048, the borders of the measured four-chunks-per-wave variant), and device-side
     counts anywhere between 0 and the capacity, must each be covered exactly once -- checked against the oracle (host counts) and
     against the same call on the truncated arrays (device counts)."""
     import ctypes
