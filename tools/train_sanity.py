@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end sanity of the training path: a student field is fitted to renders of a teacher field (synthetic scene, the reference's
-default sampler configuration, occupancy refresh every 16 steps, colour + event bundles through train_step_bundles) for a few hundred
+default sampler configuration, occupancy refresh every 16 steps, colour + event bundles through train_step_bundles; second argument
+"mlp": with the two MLP intensity mappers instead of identity / powpow) for a few hundred
 steps, once with the eager step, once with the captured step (lsenerf_amd.graph.GraphedTrainStep) and once with the captured step that
 marches the next step's rays on a side stream.  Prints the loss curves; they must fall together (same rays, same targets; the jitter streams differ).  usage: python tools/train_sanity.py [steps]"""
 import json
@@ -20,6 +21,8 @@ torch.cuda.set_device(dev)
 _lib.load()
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 cfg = dict(use_mapping=True, mapping_method="identity", map_mode="co_map", evs_mapping_method="powpow")
+if len(sys.argv) > 2 and sys.argv[2] == "mlp":       # the MLP intensity mappers of R:lse_nerf/intensity_mappers.py:28-62, trained inside the
+    cfg = dict(use_mapping=True, mapping_method="rgb_mlp", map_mode="co_map", evs_mapping_method="mlp")     # fused loss epilogue (ABI 6)
 torch.manual_seed(1)
 teacher = LSENeRFModel(LSENeRFModelConfig(**cfg), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=64).to(dev).train()
 with torch.no_grad():
